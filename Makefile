@@ -1,0 +1,28 @@
+# Top-level build: the C-ABI HIP library (libmpt_hip.so), the host C++ library + CLI, and the oracle.
+HIPCC     ?= /opt/rocm/bin/hipcc
+ARCH      ?= gfx950
+CXX       ?= g++
+PKG       := metalpathtracer_amd
+LIBDIR    := $(PKG)/lib
+# -ffp-contract=off: every FP32 expression is a sequence of single IEEE operations, so the device
+# result matches the oracle bit for bit (DESIGN.md "Parity").  Correctly rounded / and sqrt are the
+# HIP default (-fhip-fp32-correctly-rounded-divide-sqrt).
+HIPFLAGS  ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
+HOSTFLAGS ?= -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wall -Wextra
+
+all: $(LIBDIR)/libmpt_hip.so host oracle
+
+$(LIBDIR)/libmpt_hip.so: $(PKG)/csrc/mpt_hip.hip $(PKG)/csrc/mpt_device.h include/mpt.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+host:
+	@if [ -f $(PKG)/csrc/host/Makefile ]; then $(MAKE) --no-print-directory -C $(PKG)/csrc/host; fi
+
+oracle:
+	$(MAKE) --no-print-directory -C oracle
+
+clean:
+	rm -rf $(LIBDIR) oracle/_build oracle/_ref
+
+.PHONY: all host oracle clean

@@ -1,0 +1,155 @@
+/* mpt.h — C ABI of the MI355X-native path-tracing hot path (libmpt_hip.so).
+ *
+ * The reference (omkhairate/MetalPathtracer) has no plugin/FFI layer: its seam is the
+ * Renderer <-> fragment-shader binding contract (buffers 0..6 + two accumulation textures,
+ * R/Renderer/Renderer.cpp:289-301 <-> R/Renderer/Shaders/Fragment.metal:10-18; byte layouts in
+ * SURVEY.md App. D).  Every entry point below replaces one piece of that contract; the cited
+ * file:line is the reference interface it stands in for.  R/ = "MetalCpp Path Tracer/".
+ *
+ * Conventions: plain pointers and sizes only; every call returns an mpt_status (0 = ok); no
+ * exceptions, printf or assert cross the boundary (the reference printf+assert(false)s,
+ * Renderer.cpp:87-91); a context is owned by one host thread and is not thread-safe (the
+ * reference is single-threaded).  Host arrays passed in are copied during the
+ * call and may be freed immediately (as Renderer.cpp:135,146,214-215 does).
+ */
+#ifndef MPT_H
+#define MPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpt_ctx mpt_ctx;
+
+typedef enum mpt_status {
+    MPT_OK = 0,
+    MPT_ERR_INVALID_ARG = 1,   /* null pointer, zero size, bad enum                                   */
+    MPT_ERR_NO_DEVICE = 2,     /* no HIP device / ordinal out of range: the product never falls back   */
+    MPT_ERR_HIP = 3,           /* a HIP runtime call failed (mpt_last_error has the text)              */
+    MPT_ERR_BAD_SCENE = 4,     /* BVH/primitive arrays are not a well-formed tree (cycle, range, ...)  */
+    MPT_ERR_NOT_READY = 5,     /* render before scene / uniforms / size were set                       */
+    MPT_ERR_OVERFLOW = 6       /* internal ray-queue capacity exceeded (a bug; never expected)         */
+} mpt_status;
+
+/* UniformsData, 144 bytes — R/Renderer/Shaders/Structs.h:23-41 == R/Renderer/Renderer.cpp:12-28
+ * (simd::float3 is 16-byte aligned; offsets in SURVEY.md App. D).                                  */
+typedef struct mpt_uniforms {
+    int32_t primitiveIndex;        /* off   0  unused by the shader                                  */
+    int32_t _pad0[3];
+    float cameraPosition[4];       /* off  16                                                        */
+    float screenSize[2];           /* off  32                                                        */
+    float _pad1[2];
+    float viewportU[4];            /* off  48                                                        */
+    float viewportV[4];            /* off  64                                                        */
+    float firstPixelPosition[4];   /* off  80                                                        */
+    float randomSeed[4];           /* off  96  literal RNG: sin-hash parameters (Random.h:32-35)     */
+    uint64_t primitiveCount;       /* off 112  material-index guard (PathTracing.h:234-236)          */
+    uint64_t triangleCount;        /* off 120  unused by the shader                                  */
+    uint64_t frameCount;           /* off 128  running-mean weight (Fragment.metal:23,63)            */
+    uint64_t totalPrimitiveCount;  /* off 136  never set by the reference                            */
+} mpt_uniforms;
+
+enum { MPT_RNG_LITERAL = 0,  /* bit-faithful to the reference's stuck PCG stream      */
+       MPT_RNG_PHILOX = 1 }; /* Philox4x32-10, counter (pixel, sample, bounce, 0): the benchmark RNG  */
+enum { MPT_BSDF_LAMBERT = 0, /* what rayColor executes (PathTracing.h:251-255)                        */
+       MPT_BSDF_SCATTER = 1 }; /* + mirror / dielectric per Scatter.h:22-43 (dead code in the ref)    */
+enum { MPT_PIPE_WAVEFRONT = 0,  /* SoA ray queues + wave64 ballot compaction (default)                */
+       MPT_PIPE_MEGAKERNEL = 1 }; /* one thread per path, whole bounce loop in registers              */
+
+typedef struct mpt_render_params {
+    int32_t rng_mode;        /* MPT_RNG_*                                                             */
+    int32_t bsdf_mode;       /* MPT_BSDF_*                                                            */
+    int32_t max_depth;       /* reference: 32 (PathTracing.h:216)                                     */
+    int32_t pipeline;        /* MPT_PIPE_*                                                            */
+    uint32_t sample_begin;   /* first sample index of this call (philox counter word 1)               */
+    uint32_t sample_count;   /* samples per pixel rendered by this call                               */
+    uint32_t seed_lo, seed_hi; /* philox key                                                          */
+    int32_t shard_rank;      /* this GPU renders 8x8 pixel tiles t with t % shard_count == shard_rank */
+    int32_t shard_count;     /* 1 = whole image                                                       */
+    uint32_t slots_per_iter; /* wavefront width (ray slots per iteration); 0 = default                */
+    uint32_t flags;          /* MPT_FLAG_*                                                            */
+} mpt_render_params;
+
+enum { MPT_FLAG_COUNT_WORK = 1u }; /* also count node visits / primitive tests (slower; for tests)    */
+
+typedef struct mpt_stats {   /* cumulative since mpt_reset_stats                                      */
+    uint64_t paths;          /* primary rays generated                                                */
+    uint64_t rays;           /* closest-hit queries (primary + bounce)                                */
+    uint64_t node_visits;    /* BVH nodes box-tested       (only with MPT_FLAG_COUNT_WORK)            */
+    uint64_t aabb_hits;      /* box tests passed           (only with MPT_FLAG_COUNT_WORK)            */
+    uint64_t prim_tests;     /* sphere + triangle tests    (only with MPT_FLAG_COUNT_WORK)            */
+    uint64_t iterations;     /* wavefront iterations launched                                         */
+    double trace_kernel_ms;  /* HIP-event time of the trace/shade kernels of the last mpt_render      */
+    double total_ms;         /* HIP-event time of the whole last mpt_render (all kernels, its stream) */
+    uint64_t trace_launches; /* trace/shade kernel launches in the last mpt_render                    */
+} mpt_stats;
+
+/* Device selection / lifetime.  Replaces MTL::CreateSystemDefaultDevice + Renderer::Renderer /
+ * ~Renderer resource ownership (R/Window/ApplicationDelegate.cpp:33, R/Renderer/Renderer.cpp:43-78). */
+int mpt_create(int device_ordinal, mpt_ctx** out);
+int mpt_destroy(mpt_ctx* ctx);
+const char* mpt_last_error(const mpt_ctx* ctx);     /* text of the last failure on this context      */
+const char* mpt_status_string(int status);
+
+/* Fragment buffers 0 (bvhNodes), 1 (primitives), 2 (materials), 6 (primitiveIndices):
+ * Renderer::updateVisibleScene / buildBuffers, R/Renderer/Renderer.cpp:127-146,199-215, fed with the
+ * arrays Scene::createBVHBuffer / createTransformsBuffer / createMaterialsBuffer /
+ * createPrimitiveIndexBuffer return (R/Scene/Scene.h:99-167).  bvh: 2 float4 per node; prims: 3
+ * float4 per primitive; mats: 2 float4 per primitive; prim_idx: one int32 per primitive.            */
+int mpt_upload_scene(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims, const float* mats,
+                     const int32_t* prim_idx, uint64_t n_prims);
+
+/* Fragment buffer 3 (uniforms): Renderer::updateUniforms / recalculateViewport,
+ * R/Renderer/Renderer.cpp:153-182,251-267.                                                          */
+int mpt_set_uniforms(mpt_ctx* ctx, const mpt_uniforms* u);
+
+/* Textures 0/1 (RGBA32F accumulation targets): Renderer::buildTextures / drawableSizeWillChange,
+ * R/Renderer/Renderer.cpp:228-241,312-321.  Clears both targets and the HDR sum.                     */
+int mpt_resize(mpt_ctx* ctx, uint32_t width, uint32_t height);
+
+/* One reference frame: swap targets, run the hot path for 1 sample/pixel with the current
+ * uniforms (frameCount as given), write the running mean into the current target —
+ * Renderer::draw, R/Renderer/Renderer.cpp:269-310 + Fragment.metal:8-72.  Asynchronous on the
+ * context's stream like MTL commit(); mpt_read_* synchronise.                                        */
+int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p);
+
+/* Batch rendering (this project's extension of the same loop): adds, for every owned pixel, the
+ * sum over [sample_begin, sample_begin+sample_count) of the per-sample clamped colour
+ * (PathTracing.h:258) into the HDR sum buffer.  Synchronous; fills the timing fields of mpt_stats.  */
+int mpt_render(mpt_ctx* ctx, const mpt_render_params* p);
+
+/* HDR sum buffer (RGBA32F, W*H*4 floats, row-major, top-left origin).  The pointer is device
+ * memory on the context's device, e.g. for an RCCL reduce by the caller.  mpt_set_sum_buffer lets
+ * the caller supply the storage (e.g. a torch tensor); pass NULL to return to the internal one.     */
+int mpt_sum_buffer(mpt_ctx* ctx, void** device_ptr, uint64_t* bytes);
+int mpt_set_sum_buffer(mpt_ctx* ctx, void* device_ptr);
+int mpt_clear_sum(mpt_ctx* ctx);
+
+/* Read-back (the reference never reads back).  read_frame: the current running-mean
+ * target of mpt_draw.  read_sum: the raw HDR sum.  Both RGBA32F, W*H*4 floats.                        */
+int mpt_read_frame(mpt_ctx* ctx, float* rgba_host);
+int mpt_read_sum(mpt_ctx* ctx, float* rgba_host);
+
+int mpt_get_stats(mpt_ctx* ctx, mpt_stats* out);
+int mpt_reset_stats(mpt_ctx* ctx);
+void* mpt_stream(mpt_ctx* ctx);                      /* hipStream_t the context launches on           */
+int mpt_synchronize(mpt_ctx* ctx);
+
+/* Device-side closest-hit for a batch of rays (unit tests of firstHitBVH, PathTracing.h:75-204).
+ * origins/directions: 3 floats per ray (host).  Outputs (host): t, primitive id (-1 = miss),
+ * normal (3 floats, flipped to face the ray), front-face flag.                                       */
+int mpt_trace_rays(mpt_ctx* ctx, const float* origins, const float* directions, uint64_t n_rays, float* t_out,
+                   int32_t* prim_out, float* normal_out, int32_t* front_out);
+
+/* RNG known-answer hooks evaluated ON THE DEVICE (Random.h:6-16 and the philox / sincos spec).      */
+int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* hash_out, float* float_out);
+int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* ctr4, const uint32_t* key2, uint64_t n, uint32_t* out4);
+int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* sin_out, float* cos_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPT_H */

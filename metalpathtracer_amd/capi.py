@@ -1,0 +1,257 @@
+"""ctypes binding of the C ABI declared in include/mpt.h (libmpt_hip.so).
+
+The HIP library is the product; there is no CPU fallback.  Loading fails loudly when the
+library has not been built, and creating a context fails loudly when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmpt_hip.so")
+
+RNG_LITERAL, RNG_PHILOX = 0, 1
+BSDF_LAMBERT, BSDF_SCATTER = 0, 1
+PIPE_WAVEFRONT, PIPE_MEGAKERNEL = 0, 1
+FLAG_COUNT_WORK = 1
+
+STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT_ERR_HIP",
+          4: "MPT_ERR_BAD_SCENE", 5: "MPT_ERR_NOT_READY", 6: "MPT_ERR_OVERFLOW"}
+
+# every symbol include/mpt.h declares (tests/test_capi_symbols.py checks header <-> library <-> this list)
+SYMBOLS = (
+    "mpt_create", "mpt_destroy", "mpt_last_error", "mpt_status_string", "mpt_upload_scene", "mpt_set_uniforms",
+    "mpt_resize", "mpt_draw", "mpt_render", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
+    "mpt_read_frame", "mpt_read_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
+    "mpt_trace_rays", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
+)
+
+
+class MptError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s failed: %s%s" % (where, STATUS.get(status, status), (" — " + detail) if detail else ""))
+
+
+class Uniforms(C.Structure):
+    """mpt_uniforms == UniformsData, 144 bytes (R/Renderer/Shaders/Structs.h:23-41)."""
+    _fields_ = [
+        ("primitiveIndex", C.c_int32), ("_pad0", C.c_int32 * 3),
+        ("cameraPosition", C.c_float * 4),
+        ("screenSize", C.c_float * 2), ("_pad1", C.c_float * 2),
+        ("viewportU", C.c_float * 4),
+        ("viewportV", C.c_float * 4),
+        ("firstPixelPosition", C.c_float * 4),
+        ("randomSeed", C.c_float * 4),
+        ("primitiveCount", C.c_uint64),
+        ("triangleCount", C.c_uint64),
+        ("frameCount", C.c_uint64),
+        ("totalPrimitiveCount", C.c_uint64),
+    ]
+
+
+assert C.sizeof(Uniforms) == 144
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("rng_mode", C.c_int32), ("bsdf_mode", C.c_int32), ("max_depth", C.c_int32), ("pipeline", C.c_int32),
+        ("sample_begin", C.c_uint32), ("sample_count", C.c_uint32),
+        ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+        ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
+        ("slots_per_iter", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("paths", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64), ("aabb_hits", C.c_uint64),
+        ("prim_tests", C.c_uint64), ("iterations", C.c_uint64),
+        ("trace_kernel_ms", C.c_double), ("total_ms", C.c_double), ("trace_launches", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """dlopen libmpt_hip.so and declare prototypes.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libmpt_hip.so is not built (%s). Run `make` or __graft_entry__.build(); "
+                          "there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, fp, ip, up = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    L.mpt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mpt_destroy.argtypes = [vp]
+    L.mpt_last_error.argtypes = [vp]
+    L.mpt_last_error.restype = C.c_char_p
+    L.mpt_status_string.argtypes = [C.c_int]
+    L.mpt_status_string.restype = C.c_char_p
+    L.mpt_upload_scene.argtypes = [vp, fp, C.c_uint64, fp, fp, ip, C.c_uint64]
+    L.mpt_set_uniforms.argtypes = [vp, C.POINTER(Uniforms)]
+    L.mpt_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.mpt_draw.argtypes = [vp, C.POINTER(RenderParams)]
+    L.mpt_render.argtypes = [vp, C.POINTER(RenderParams)]
+    L.mpt_sum_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.mpt_set_sum_buffer.argtypes = [vp, vp]
+    L.mpt_clear_sum.argtypes = [vp]
+    L.mpt_read_frame.argtypes = [vp, fp]
+    L.mpt_read_sum.argtypes = [vp, fp]
+    L.mpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.mpt_reset_stats.argtypes = [vp]
+    L.mpt_stream.argtypes = [vp]
+    L.mpt_stream.restype = vp
+    L.mpt_synchronize.argtypes = [vp]
+    L.mpt_trace_rays.argtypes = [vp, fp, fp, C.c_uint64, fp, ip, fp, ip]
+    L.mpt_kat_pcg.argtypes = [vp, up, C.c_uint64, up, fp]
+    L.mpt_kat_philox.argtypes = [vp, up, up, C.c_uint64, up]
+    L.mpt_kat_sincos.argtypes = [vp, fp, C.c_uint64, fp, fp]
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Context:
+    """Owns one mpt_ctx (one GPU, one stream).  Not thread-safe, like the reference Renderer."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.mpt_create(int(device), C.byref(self.h))
+        if rc:
+            raise MptError(rc, "mpt_create", "a MI355X GPU is required; there is no CPU fallback")
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mpt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc:
+            raise MptError(rc, where, (self.L.mpt_last_error(self.h) or b"").decode())
+
+    def upload_scene(self, bvh, prims, mats, prim_idx):
+        bvh = np.ascontiguousarray(bvh, np.float32)
+        prims = np.ascontiguousarray(prims, np.float32)
+        mats = np.ascontiguousarray(mats, np.float32)
+        prim_idx = np.ascontiguousarray(prim_idx, np.int32)
+        n_nodes = bvh.size // 8
+        n_prims = prims.size // 12
+        if mats.size != n_prims * 8 or prim_idx.size != n_prims:
+            raise ValueError("scene arrays disagree on the primitive count")
+        self._chk(self.L.mpt_upload_scene(self.h, _fp(bvh), n_nodes, _fp(prims), _fp(mats), _ip(prim_idx), n_prims),
+                  "mpt_upload_scene")
+
+    def set_uniforms(self, u):
+        self._chk(self.L.mpt_set_uniforms(self.h, C.byref(u)), "mpt_set_uniforms")
+
+    def resize(self, w, h):
+        self._chk(self.L.mpt_resize(self.h, int(w), int(h)), "mpt_resize")
+        self.width, self.height = int(w), int(h)
+
+    @staticmethod
+    def params(rng_mode=RNG_PHILOX, bsdf_mode=BSDF_LAMBERT, max_depth=32, pipeline=PIPE_WAVEFRONT, sample_begin=0,
+               sample_count=1, seed=(1, 0), shard_rank=0, shard_count=1, slots_per_iter=0, flags=0):
+        return RenderParams(rng_mode, bsdf_mode, max_depth, pipeline, sample_begin, sample_count, seed[0], seed[1],
+                            shard_rank, shard_count, slots_per_iter, flags)
+
+    def draw(self, **kw):
+        p = self.params(**kw)
+        self._chk(self.L.mpt_draw(self.h, C.byref(p)), "mpt_draw")
+
+    def render(self, **kw):
+        p = self.params(**kw)
+        self._chk(self.L.mpt_render(self.h, C.byref(p)), "mpt_render")
+
+    def clear_sum(self):
+        self._chk(self.L.mpt_clear_sum(self.h), "mpt_clear_sum")
+
+    def sum_buffer(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.mpt_sum_buffer(self.h, C.byref(p), C.byref(n)), "mpt_sum_buffer")
+        return p.value, n.value
+
+    def set_sum_buffer(self, device_ptr):
+        self._chk(self.L.mpt_set_sum_buffer(self.h, C.c_void_p(device_ptr)), "mpt_set_sum_buffer")
+
+    def read_frame(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._chk(self.L.mpt_read_frame(self.h, _fp(out)), "mpt_read_frame")
+        return out
+
+    def read_sum(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._chk(self.L.mpt_read_sum(self.h, _fp(out)), "mpt_read_sum")
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.mpt_get_stats(self.h, C.byref(s)), "mpt_get_stats")
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._chk(self.L.mpt_reset_stats(self.h), "mpt_reset_stats")
+
+    def synchronize(self):
+        self._chk(self.L.mpt_synchronize(self.h), "mpt_synchronize")
+
+    def stream(self):
+        return self.L.mpt_stream(self.h)
+
+    def trace_rays(self, origins, directions):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n, np.float32)
+        prim = np.empty(n, np.int32)
+        nrm = np.empty((n, 3), np.float32)
+        front = np.empty(n, np.int32)
+        self._chk(self.L.mpt_trace_rays(self.h, _fp(o), _fp(d), n, _fp(t), _ip(prim), _fp(nrm), _ip(front)),
+                  "mpt_trace_rays")
+        return t, prim, nrm, front
+
+    def kat_pcg(self, seeds):
+        s = np.ascontiguousarray(seeds, np.uint32)
+        h = np.empty_like(s)
+        f = np.empty(s.shape, np.float32)
+        self._chk(self.L.mpt_kat_pcg(self.h, _up(s), s.size, _up(h), _fp(f)), "mpt_kat_pcg")
+        return h, f
+
+    def kat_philox(self, ctr, key):
+        c = np.ascontiguousarray(ctr, np.uint32).reshape(-1, 4)
+        k = np.ascontiguousarray(key, np.uint32).reshape(-1, 2)
+        o = np.empty_like(c)
+        self._chk(self.L.mpt_kat_philox(self.h, _up(c), _up(k), c.shape[0], _up(o)), "mpt_kat_philox")
+        return o
+
+    def kat_sincos(self, u):
+        u = np.ascontiguousarray(u, np.float32)
+        s = np.empty_like(u)
+        c = np.empty_like(u)
+        self._chk(self.L.mpt_kat_sincos(self.h, _fp(u), u.size, _fp(s), _fp(c)), "mpt_kat_sincos")
+        return s, c

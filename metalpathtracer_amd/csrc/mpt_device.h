@@ -1,0 +1,346 @@
+// mpt_device.h — device-side building blocks of the hot path (gfx950 only).
+//
+// Restated from the reference's Metal shader (R/ = "MetalCpp Path Tracer/"):
+//   RNG            R/Renderer/Shaders/Random.h:6-16
+//   unit vector    R/Renderer/Shaders/PathTracing.h:25-31
+//   slab test      R/Renderer/Shaders/PathTracing.h:52-72
+//   closest hit    R/Renderer/Shaders/PathTracing.h:75-204
+//   shading        R/Renderer/Shaders/PathTracing.h:207-259, Scatter.h:10-43
+// but laid out for CDNA4: a stackless (threaded) BVH whose hot nodes live in LDS, primitives
+// pre-gathered into leaf order (no index indirection), a de-duplicated material table.
+//
+// FP contract: this translation unit is compiled with -ffp-contract=off; every expression below is
+// a sequence of single IEEE-754 binary32 operations in the same order as oracle/mpt_oracle.cpp, so
+// the two agree bit for bit wherever libm is not involved (DESIGN.md "Parity").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MPT_WAVE 64
+#define MPT_NSHARD 16
+#define MPT_NGROUP 8          // work-cursor groups (one per XCD under round-robin placement)
+#define MPT_NONE 0xFFFFFFFFu
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return F3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {
+    return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// normalize = v * (1 / sqrt(dot(v,v))) — same definition as the oracle (see its comment).
+__device__ __forceinline__ F3 normalize3(F3 a) {
+    float inv = 1.0f / sqrtf(dot3(a, a));
+    return a * inv;
+}
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+// ---- RNG ------------------------------------------------------------------------------------------
+// Random.h:6-11 — PCG-RXS-M-XS without the final multiply.
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t s) {
+    uint32_t state = s * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state);
+    return (word >> 22u) ^ word;
+}
+// Random.h:13-16 — seed by value; may return exactly 1.0f.
+__device__ __forceinline__ float pcg_float(uint32_t s) { return (float)pcg_hash(s) / 4294967296.0f; }
+
+// Philox4x32-10; counter (pixel, sample, bounce, 0), key (seed_lo, seed_hi).
+struct U4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
+// sin/cos(2*pi*u), u in [0,1): exact quadrant reduction on u, Taylor polynomials on [-pi/4,pi/4].
+__device__ __forceinline__ void sincos_2pi(float u, float& s_out, float& c_out) {
+    float x = u * 4.0f;
+    int q = (int)(x + 0.5f);
+    float r = x - (float)q;
+    float th = r * 1.57079637050628662109375f;
+    float t2 = th * th;
+    float ps = -1.98412701138295233249664306640625e-4f + t2 * 2.755731884462875314056873321533203125e-6f;
+    ps = 8.3333337679505348205566406250e-3f + t2 * ps;
+    ps = -0.16666667163372039794921875f + t2 * ps;
+    float s = th + (th * t2) * ps;
+    float pc = -1.38888892251998186111450195312500e-3f + t2 * 2.48015876422869041562080383300781250e-5f;
+    pc = 4.1666667908430099487304687500e-2f + t2 * pc;
+    pc = -0.5f + t2 * pc;
+    float c = 1.0f + t2 * pc;
+    int k = q & 3;
+    s_out = (k == 0) ? s : (k == 1) ? c : (k == 2) ? -s : -c;
+    c_out = (k == 0) ? c : (k == 1) ? -s : (k == 2) ? -c : s;
+}
+
+// ---- scene on the device ----------------------------------------------------------------------------
+// Threaded BVH node, 32 bytes (same size as the reference's, SURVEY App. D buf 0):
+//   n0 = (bmin.xyz, A)   n1 = (bmax.xyz, B)
+//   internal (B >= 0): box hit -> go to A (first child in the reference's visit order: the RIGHT child,
+//                       PathTracing.h:191-193), box miss -> go to B (skip the subtree)
+//   leaf     (B <  0): -(B+1) = first*16 + (count-1); after the leaf (hit or miss) go to A
+//   index >= n_nodes terminates.  Nodes are stored breadth-first so that the first n_lds nodes (top
+//   of the tree) can be staged in LDS.
+// Device primitive, 48 bytes, stored in leaf order:
+//   triangle: (v0.xyz, 1.0f) (e1.xyz, bits(mat)) (e2.xyz, bits(orig id))     e1 = v1-v0, e2 = v2-v0
+//   sphere:   (c.xyz,  0.0f) (r,0,0, bits(mat)) (0,0,0,  bits(orig id))
+struct SceneDev {
+    const float4* nodes;
+    const float4* prims;
+    const float4* mats;   // 2 float4 per unique material: (albedo, type) (emission, power)
+    uint32_t n_nodes;
+    uint32_t n_lds_nodes;  // nodes [0, n_lds_nodes) are also in LDS
+    uint32_t n_prims;
+    uint32_t n_mats;
+};
+
+struct WorkCount {
+    uint32_t node_visits, aabb_hits, prim_tests;
+};
+
+// Closest hit — PathTracing.h:75-204.  Visits nodes and tests primitives in exactly the reference's
+// order (right child first, leaf primitives in index order), so ties resolve identically.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const SceneDev& sc, const float4* __restrict__ lds_nodes, F3 o, F3 d,
+                                            float& best_t, int& best_prim, WorkCount& wc) {
+    const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;  // PathTracing.h:61 (per call there)
+    best_t = INFINITY;
+    best_prim = -1;
+    uint32_t i = 0;
+    const uint32_t n_nodes = sc.n_nodes, n_lds = sc.n_lds_nodes;
+    while (i < n_nodes) {
+        float4 n0, n1;
+        if (i < n_lds) {
+            n0 = lds_nodes[2 * i];
+            n1 = lds_nodes[2 * i + 1];
+        } else {
+            n0 = sc.nodes[2 * i];
+            n1 = sc.nodes[2 * i + 1];
+        }
+        // PathTracing.h:52-72 slab test with tMin = 1e-4, tMax = best t.  The per-axis early-outs
+        // are equivalent to one test after the third axis (tMin only grows, tMax only shrinks).
+        float t0 = (n0.x - o.x) * idx, t1 = (n1.x - o.x) * idx;
+        float lo = fmaxf(0.0001f, idx < 0.0f ? t1 : t0);
+        float hi = fminf(best_t, idx < 0.0f ? t0 : t1);
+        t0 = (n0.y - o.y) * idy;
+        t1 = (n1.y - o.y) * idy;
+        lo = fmaxf(lo, idy < 0.0f ? t1 : t0);
+        hi = fminf(hi, idy < 0.0f ? t0 : t1);
+        t0 = (n0.z - o.z) * idz;
+        t1 = (n1.z - o.z) * idz;
+        lo = fmaxf(lo, idz < 0.0f ? t1 : t0);
+        hi = fminf(hi, idz < 0.0f ? t0 : t1);
+        const bool box = hi > lo;
+        const int A = __float_as_int(n0.w), B = __float_as_int(n1.w);
+        if (COUNT) {
+            wc.node_visits++;
+            wc.aabb_hits += box ? 1u : 0u;
+        }
+        if (B >= 0) {
+            i = box ? (uint32_t)A : (uint32_t)B;
+            continue;
+        }
+        if (box) {
+            const uint32_t enc = (uint32_t)(-(B + 1));
+            const uint32_t first = enc >> 4, count = (enc & 15u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 p0 = sc.prims[3 * (first + k)];
+                const float4 p1 = sc.prims[3 * (first + k) + 1];
+                if (COUNT) wc.prim_tests++;
+                const int ptype = (int)p0.w;
+                if (ptype == 1) {  // PathTracing.h:143-176 Moeller-Trumbore, two-sided
+                    const float4 p2 = sc.prims[3 * (first + k) + 2];
+                    F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
+                    F3 h = cross3(d, e2);
+                    float a = dot3(e1, h);
+                    if (fabsf(a) > 1e-5f) {
+                        float f = 1.0f / a;
+                        F3 s = o - v0;
+                        float u = f * dot3(s, h);
+                        if (u >= 0.0f && u <= 1.0f) {
+                            F3 q = cross3(s, e1);
+                            float v = f * dot3(d, q);
+                            if (v >= 0.0f && u + v <= 1.0f) {
+                                float tt = f * dot3(e2, q);
+                                if (tt > 0.0001f && tt < best_t) {
+                                    best_t = tt;
+                                    best_prim = (int)(first + k);
+                                }
+                            }
+                        }
+                    }
+                } else if (ptype == 0) {  // PathTracing.h:120-142 sphere, near root only
+                    F3 c = f3(p0.x, p0.y, p0.z);
+                    float radius = p1.x;
+                    F3 oc = o - c;
+                    float a = dot3(d, d);
+                    float b = dot3(oc, d);
+                    float cc = dot3(oc, oc) - radius * radius;
+                    float disc = b * b - a * cc;
+                    if (disc > 0.0f) {
+                        float sq = sqrtf(disc);
+                        float temp = (-b - sq) / a;
+                        if (temp < best_t && temp > 0.0001f) {
+                            best_t = temp;
+                            best_prim = (int)(first + k);
+                        }
+                    }
+                }
+            }
+        }
+        i = (uint32_t)A;
+    }
+}
+
+struct HitInfo {
+    F3 point, normal;
+    bool front;
+    int mat;      // material table index
+    int orig_id;  // primitive id in the caller's numbering
+};
+// Surface point / geometric normal of the winning primitive — the values PathTracing.h:138-139,
+// 168-169 compute when the hit is accepted, and the front-face flip of :196-201.
+__device__ __forceinline__ HitInfo finish_hit(const SceneDev& sc, F3 o, F3 d, float t, int prim) {
+    HitInfo h;
+    const float4 p0 = sc.prims[3 * prim], p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
+    h.point = o + t * d;
+    if ((int)p0.w == 1) {
+        h.normal = normalize3(cross3(f3(p1.x, p1.y, p1.z), f3(p2.x, p2.y, p2.z)));
+    } else {
+        h.normal = normalize3(h.point - f3(p0.x, p0.y, p0.z));
+    }
+    h.mat = __float_as_int(p1.w);
+    h.orig_id = __float_as_int(p2.w);
+    h.front = dot3(h.normal, d) < 0.0f;
+    if (!h.front) h.normal = -h.normal;
+    return h;
+}
+
+// ---- per-path state and shading --------------------------------------------------------------------------
+struct PathState {
+    F3 o, d;
+    F3 thr;        // absorption.rgb (PathTracing.h:218)
+    F3 L;          // light.rgb      (PathTracing.h:219)
+    float La;      // light.a (absorption.a stays 1)
+    uint32_t path; // path index inside the pass
+    uint32_t bounce;
+};
+
+struct ShadeParams {
+    int rng_mode, bsdf_mode, max_depth;
+    uint32_t seed_lo, seed_hi;
+    uint32_t primitive_count;  // uniforms.primitiveCount (material guard, PathTracing.h:234-236)
+};
+
+struct PathRngDev {
+    uint32_t pixel, sample;  // philox counter words 0,1
+    uint32_t lit_seed;       // literal: the stuck seed entering rayColor
+};
+
+// PathTracing.h:25-31 (literal: same u for z and phi, seed never advances).
+__device__ __forceinline__ F3 random_unit_vector(const ShadeParams& sp, const PathRngDev& g, uint32_t bounce,
+                                                 float& u_extra) {
+    float z, s, c;
+    if (sp.rng_mode == 0) {
+        float u = pcg_float(g.lit_seed);
+        z = 2.0f * u - 1.0f;
+        float t = 2.0f * 3.14159274101257324f * u;
+        s = sinf(t);
+        c = cosf(t);
+        u_extra = u;
+    } else {
+        U4 r = philox4x32_10(g.pixel, g.sample, bounce, 0u, sp.seed_lo, sp.seed_hi);
+        z = 2.0f * u01(r.x) - 1.0f;
+        sincos_2pi(u01(r.y), s, c);
+        u_extra = u01(r.z);
+    }
+    float rr = sqrtf(1.0f - z * z);
+    return f3(rr * c, rr * s, z);
+}
+
+__device__ __forceinline__ F3 reflect3(F3 i, F3 n) { return i - 2.0f * dot3(n, i) * n; }
+__device__ __forceinline__ F3 refract3(F3 i, F3 n, float eta) {
+    float dd = dot3(n, i);
+    float k = 1.0f - eta * eta * (1.0f - dd * dd);
+    if (k < 0.0f) return f3(0, 0, 0);
+    return eta * i - (eta * dd + sqrtf(k)) * n;
+}
+// Scatter.h:10-20
+__device__ __forceinline__ bool mirror_angle(float ri, F3 normal, F3 rayDir, float u) {
+    float cosT = dot3(-1.0f * rayDir, normal);
+    float sinT = sqrtf(1.0f - cosT * cosT);
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float m = 1.0f - cosT;
+    float m2 = m * m;
+    float refl = r0 + (1.0f - r0) * (m2 * m2 * m);
+    return (ri * sinT > 1.0f) || (refl > u);
+}
+
+// One iteration of the bounce loop of rayColor (PathTracing.h:221-256) for a ray whose closest hit is
+// (t, prim).  Returns true if the path continues (ps holds the next ray), false if it ended (ps.L/La
+// hold the final light, to be clamped by the caller: PathTracing.h:258).
+__device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const ShadeParams& sp, const PathRngDev& g,
+                                             PathState& ps, float t, int prim) {
+    if (prim < 0) {  // PathTracing.h:225-232 sky
+        F3 ud = normalize3(ps.d);
+        float tt = 0.5f * (ud.y + 1.0f);
+        F3 sky = f3(1.0f + (0.6f - 1.0f) * tt, 1.0f + (0.7f - 1.0f) * tt, 1.0f + (1.0f - 1.0f) * tt);
+        ps.L.x += ps.thr.x * sky.x;
+        ps.L.y += ps.thr.y * sky.y;
+        ps.L.z += ps.thr.z * sky.z;
+        ps.La += 1.0f;
+        return false;
+    }
+    HitInfo h = finish_hit(sc, ps.o, ps.d, t, prim);
+    if ((uint32_t)h.orig_id >= sp.primitive_count) return false;  // PathTracing.h:234-236
+    const float4 m0 = sc.mats[2 * h.mat], m1 = sc.mats[2 * h.mat + 1];
+    const float mtype = m0.w, power = m1.w;
+    if (power > 0.0f || mtype == 2.0f) {  // PathTracing.h:245-249
+        ps.L.x += ps.thr.x * m1.x * power;
+        ps.L.y += ps.thr.y * m1.y * power;
+        ps.L.z += ps.thr.z * m1.z * power;
+        ps.La += power;
+    }
+    float u_extra;
+    F3 ruv = random_unit_vector(sp, g, ps.bounce, u_extra);
+    F3 nd;
+    bool through = false;
+    if (sp.bsdf_mode == 0 || mtype == 0.0f) {
+        nd = normalize3(h.normal + ruv);  // PathTracing.h:252-254
+    } else if (mtype < 0.0f) {            // Scatter.h:28-31
+        nd = normalize3(reflect3(ps.d, h.normal));
+    } else {                              // Scatter.h:32-40
+        float ri = h.front ? 1.0f / mtype : mtype;
+        nd = mirror_angle(ri, h.normal, ps.d, u_extra) ? reflect3(ps.d, h.normal) : refract3(ps.d, h.normal, ri);
+        nd = normalize3(nd);
+        through = dot3(nd, h.normal) < 0.0f;
+    }
+    ps.o = through ? h.point - 0.0001f * h.normal : h.point + 0.0001f * h.normal;  // PathTracing.h:253
+    ps.d = nd;
+    ps.thr.x *= m0.x;  // PathTracing.h:255
+    ps.thr.y *= m0.y;
+    ps.thr.z *= m0.z;
+    ps.bounce++;
+    return (int)ps.bounce < sp.max_depth;
+}

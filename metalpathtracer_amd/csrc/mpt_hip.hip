@@ -1,0 +1,1274 @@
+// mpt_hip.hip — kernels and C ABI (include/mpt.h) of the MI355X path-tracing hot path.
+//
+// Pipeline (MPT_PIPE_WAVEFRONT, the default):
+//   k_begin_pass        reset the pass descriptor
+//   repeat until the pass drains:
+//     k_step            persistent workgroups; each WAVE pulls 64-slot work items from per-XCD cursors.
+//                       An item is either 64 consecutive entries of the SoA input ray queue or 64 new
+//                       paths (primary rays are generated in registers and never touch HBM).  Per item:
+//                       closest hit against the LDS-staged threaded BVH, one bounce of shading, then the
+//                       surviving rays are compacted with a wave64 ballot + mbcnt prefix and appended to
+//                       the output queue with ONE atomic per wave (sharded counters).  Finished paths
+//                       write their clamped radiance to a per-path slot.
+//     k_advance         one wave: turn the output counters into the next iteration's descriptor
+//   k_resolve_*         per pixel: sum the per-path slots in sample order into the HDR sum (or apply the
+//                       reference's running-mean frame protocol, Fragment.metal:62-69)
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mpt.h"
+#include "mpt_device.h"
+
+// =====================================================================================================
+// device-side structures
+// =====================================================================================================
+struct QueueDev {  // struct-of-arrays ray queue, 16-byte records -> dwordx4 per lane, 1 KiB per wave access
+    float4* od;    // (o.x, o.y, o.z, d.x)
+    float4* dt;    // (d.y, d.z, thr.r, thr.g)
+    float4* tl;    // (thr.b, L.r, L.g, L.b)
+    uint2* ia;     // (path | bounce << 27, bits(L.a))
+};
+
+struct PassDesc {
+    // written by k_advance, read by k_step
+    uint32_t in_count[MPT_NSHARD];
+    uint32_t item_prefix[MPT_NSHARD + 1];  // queue items of shards [0,s) ; [NSHARD] = all queue items
+    uint32_t n_items;
+    uint32_t regen_base;
+    uint32_t range_end[MPT_NGROUP];
+    // atomics
+    uint32_t cursor[MPT_NGROUP];
+    uint32_t out_count[MPT_NSHARD];
+    // pass state
+    uint32_t next_path, total_paths;
+    uint32_t slots_items;  // wavefront width in 64-slot items
+    uint32_t done, overflow, iterations;
+    unsigned long long paths, rays, node_visits, aabb_hits, prim_tests;
+};
+
+struct PassParams {
+    SceneDev scene;
+    QueueDev q[2];
+    uint32_t shard_cap;
+    PassDesc* desc;
+    float4* slots;               // per-path final radiance (clamped), index = path
+    const uint32_t* pixel_seed;  // literal RNG: per-pixel u32 seed (host sin-hash, Fragment.metal:29)
+    // camera (mpt_uniforms)
+    F3 cam, first, vu, vv;
+    float W, H;
+    uint32_t width, height, tiles_x;
+    uint32_t S, sample_begin;    // samples per pixel in this pass, first sample index
+    uint32_t rank, nranks;
+    ShadeParams sp;
+    volatile uint32_t* host_done;
+};
+
+// path index -> pixel.  path = ((tile_local * S) + s) * 64 + lane; a wave = one 8x8 pixel tile.
+__device__ __forceinline__ bool path_to_pixel(const PassParams& pp, uint32_t path, uint32_t& px, uint32_t& py,
+                                              uint32_t& s) {
+    uint32_t lane = path & 63u, chunk = path >> 6;
+    uint32_t tl = chunk / pp.S;
+    s = chunk - tl * pp.S;
+    uint32_t T = tl * pp.nranks + pp.rank;
+    uint32_t ty = T / pp.tiles_x, tx = T - ty * pp.tiles_x;
+    px = tx * 8u + (lane & 7u);
+    py = ty * 8u + (lane >> 3);
+    return px < pp.width && py < pp.height;
+}
+
+// Fragment.metal:29-42 — seed, sub-pixel jitter, primary ray.
+__device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, uint32_t sample,
+                                            PathState& ps, PathRngDev& g) {
+    float uvx = ((float)px + 0.5f) / pp.W, uvy = ((float)py + 0.5f) / pp.H;  // Vertex.metal:5-17
+    float xOff, yOff;
+    g.pixel = py * pp.width + px;
+    g.sample = sample;
+    if (pp.sp.rng_mode == 0) {
+        uint32_t seed = pp.pixel_seed[g.pixel];
+        xOff = (pcg_float(seed) - 0.5f) / pp.W;
+        seed = pcg_hash(seed);
+        yOff = (pcg_float(seed) - 0.5f) / pp.H;
+        seed = pcg_hash(seed);
+        g.lit_seed = seed;
+    } else {
+        U4 r = philox4x32_10(g.pixel, sample, 0xFFFFFFFFu, 0u, pp.sp.seed_lo, pp.sp.seed_hi);
+        xOff = (u01(r.x) - 0.5f) / pp.W;
+        yOff = (u01(r.y) - 0.5f) / pp.H;
+        g.lit_seed = 0;
+    }
+    F3 dir = (pp.first + (uvx + xOff) * pp.vu + (uvy + yOff) * pp.vv) - pp.cam;
+    ps.o = pp.cam;
+    ps.d = normalize3(dir);
+    ps.thr = f3(1, 1, 1);
+    ps.L = f3(0, 0, 0);
+    ps.La = 0.0f;
+    ps.bounce = 0;
+}
+
+// literal RNG: the seed entering rayColor is a pure function of the pixel; recompute it for bounce rays
+__device__ __forceinline__ void rng_for_path(const PassParams& pp, uint32_t path, PathRngDev& g) {
+    uint32_t px, py, s;
+    path_to_pixel(pp, path, px, py, s);
+    g.pixel = py * pp.width + px;
+    g.sample = pp.sample_begin + s;
+    g.lit_seed = 0;
+    if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+}
+
+__device__ __forceinline__ void stage_nodes(const SceneDev& sc, float4* lds) {
+    const uint32_t n4 = sc.n_lds_nodes * 2u;
+    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = sc.nodes[i];
+    __syncthreads();
+}
+
+// wave-uniform work-item fetch from the per-group cursors (home group first, then steal)
+// (every lane of the wave is active here, so readfirstlane returns lane 0's value as an SGPR)
+__device__ __forceinline__ uint32_t fetch_item(PassDesc* desc, const uint32_t* s_range_end, uint32_t home) {
+    uint32_t item = MPT_NONE;
+    if ((threadIdx.x & 63u) == 0) {
+        for (uint32_t t = 0; t < MPT_NGROUP; ++t) {
+            uint32_t g = (home + t) & (MPT_NGROUP - 1);
+            uint32_t end = s_range_end[g];
+            if (__hip_atomic_load(&desc->cursor[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= end) continue;
+            uint32_t k = atomicAdd(&desc->cursor[g], 1u);
+            if (k < end) {
+                item = k;
+                break;
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(item);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(1024) void k_step(PassParams pp, uint32_t parity) {
+    extern __shared__ float4 lds_nodes[];
+    PassDesc* desc = pp.desc;
+    // iteration descriptor -> LDS, behind the node image (16-byte aligned: n_lds_nodes * 32 bytes)
+    uint32_t* s_prefix = (uint32_t*)(lds_nodes + 2 * pp.scene.n_lds_nodes);  // [NSHARD+1]
+    uint32_t* s_incount = s_prefix + (MPT_NSHARD + 1);                        // [NSHARD]
+    uint32_t* s_range_end = s_incount + MPT_NSHARD;                          // [NGROUP]
+    if (threadIdx.x <= MPT_NSHARD) s_prefix[threadIdx.x] = desc->item_prefix[threadIdx.x];
+    if (threadIdx.x < MPT_NSHARD) s_incount[threadIdx.x] = desc->in_count[threadIdx.x];
+    if (threadIdx.x < MPT_NGROUP) s_range_end[threadIdx.x] = desc->range_end[threadIdx.x];
+    stage_nodes(pp.scene, lds_nodes);
+
+    const QueueDev qin = pp.q[parity], qout = pp.q[parity ^ 1u];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t home = blockIdx.x & (MPT_NGROUP - 1);
+    const uint32_t nq_items = s_prefix[MPT_NSHARD];
+    const uint32_t total_paths = desc->total_paths;
+    const uint32_t regen_base = desc->regen_base;
+    uint32_t n_rays = 0, n_paths = 0;
+    WorkCount wc = {0, 0, 0};
+
+    for (;;) {
+        const uint32_t item = fetch_item(desc, s_range_end, home);
+        if (item == MPT_NONE) break;
+        PathState ps;
+        PathRngDev g;
+        bool valid;
+        if (item < nq_items) {  // 64 entries of the input queue
+            uint32_t s = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < MPT_NSHARD; ++k) s += (item >= s_prefix[k]) ? 1u : 0u;
+            const uint32_t idx = (item - s_prefix[s]) * 64u + lane;
+            valid = idx < s_incount[s];
+            if (valid) {
+                const uint32_t at = s * pp.shard_cap + idx;
+                const float4 a = qin.od[at], b = qin.dt[at], c = qin.tl[at];
+                const uint2 ia = qin.ia[at];
+                ps.o = f3(a.x, a.y, a.z);
+                ps.d = f3(a.w, b.x, b.y);
+                ps.thr = f3(b.z, b.w, c.x);
+                ps.L = f3(c.y, c.z, c.w);
+                ps.La = __uint_as_float(ia.y);
+                ps.path = ia.x & 0x07FFFFFFu;
+                ps.bounce = ia.x >> 27;
+                rng_for_path(pp, ps.path, g);
+            }
+        } else {  // 64 new paths: one 8x8 pixel tile at one sample index
+            ps.path = regen_base + (item - nq_items) * 64u + lane;
+            valid = ps.path < total_paths;
+            if (valid) {
+                uint32_t px, py, s;
+                valid = path_to_pixel(pp, ps.path, px, py, s);
+                if (valid) {
+                    gen_primary(pp, px, py, pp.sample_begin + s, ps, g);
+                    n_paths++;
+                }
+            }
+        }
+        bool alive = false;
+        if (valid) {
+            float t;
+            int prim;
+            closest_hit<COUNT>(pp.scene, lds_nodes, ps.o, ps.d, t, prim, wc);
+            n_rays++;
+            alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
+            if (!alive)  // PathTracing.h:258 per-sample clamp
+                pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+        }
+        // wave64 stream compaction: ballot + prefix popcount, one atomic per wave
+        const unsigned long long mask = __ballot(alive);
+        if (mask != 0ull) {
+            const uint32_t n = (uint32_t)__popcll(mask);
+            const uint32_t shard = item & (MPT_NSHARD - 1);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&desc->out_count[shard], n);
+            base = __shfl(base, 0);
+            if (alive) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const uint32_t idx = base + rank;
+                if (idx < pp.shard_cap) {
+                    const uint32_t at = shard * pp.shard_cap + idx;
+                    qout.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+                    qout.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+                    qout.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+                    qout.ia[at] = make_uint2(ps.path | (ps.bounce << 27), __float_as_uint(ps.La));
+                } else {
+                    desc->overflow = 1u;
+                }
+            }
+        }
+    }
+    // per-wave statistics: reduce over lanes, one atomic per counter per wave
+    unsigned long long r = n_rays, p = n_paths;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        p += __shfl_down(p, off);
+    }
+    if (COUNT) {
+        unsigned long long a = wc.node_visits, b = wc.aabb_hits, c = wc.prim_tests;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+            c += __shfl_down(c, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&desc->node_visits, a);
+            atomicAdd(&desc->aabb_hits, b);
+            atomicAdd(&desc->prim_tests, c);
+        }
+    }
+    if (lane == 0 && (r | p)) {
+        atomicAdd(&desc->rays, r);
+        atomicAdd(&desc->paths, p);
+    }
+}
+
+// one wave; lane 0 does the (tiny) serial work
+__device__ void advance_desc(PassDesc* d, volatile uint32_t* host_done) {
+    uint32_t items = 0;
+    for (uint32_t s = 0; s < MPT_NSHARD; ++s) {
+        uint32_t c = d->out_count[s];
+        d->in_count[s] = c;
+        d->out_count[s] = 0;
+        d->item_prefix[s] = items;
+        items += (c + 63u) >> 6;
+    }
+    d->item_prefix[MPT_NSHARD] = items;
+    uint32_t room = d->slots_items > items ? d->slots_items - items : 0u;
+    uint32_t left = (d->total_paths - d->next_path) >> 6;
+    uint32_t regen = room < left ? room : left;
+    d->regen_base = d->next_path;
+    d->next_path += regen * 64u;
+    uint32_t n = items + regen;
+    d->n_items = n;
+    for (uint32_t g = 0; g < MPT_NGROUP; ++g) {
+        uint32_t b = (uint32_t)(((unsigned long long)n * g) / MPT_NGROUP);
+        uint32_t e = (uint32_t)(((unsigned long long)n * (g + 1)) / MPT_NGROUP);
+        d->cursor[g] = b;
+        d->range_end[g] = e;
+    }
+    d->done = (n == 0) ? 1u : 0u;
+    if (n != 0) d->iterations++;
+    if (host_done) *host_done = d->done | (d->overflow << 1);
+}
+
+__global__ void k_begin_pass(PassDesc* d, uint32_t total_paths, uint32_t slots_items, volatile uint32_t* host_done) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (uint32_t s = 0; s < MPT_NSHARD; ++s) d->out_count[s] = 0;
+    d->next_path = 0;
+    d->total_paths = total_paths;
+    d->slots_items = slots_items;
+    d->overflow = 0;
+    advance_desc(d, host_done);
+}
+
+__global__ void k_advance(PassDesc* d, volatile uint32_t* host_done) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    advance_desc(d, host_done);
+}
+
+// Megakernel variant: one thread per path, whole bounce loop in registers (A/B baseline).
+template <bool COUNT>
+__global__ __launch_bounds__(1024) void k_megakernel(PassParams pp) {
+    extern __shared__ float4 lds_nodes[];
+    stage_nodes(pp.scene, lds_nodes);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_paths = pp.desc->total_paths;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    uint32_t n_rays = 0, n_paths = 0;
+    WorkCount wc = {0, 0, 0};
+    for (uint32_t chunk = blockIdx.x * waves_per_block + (threadIdx.x >> 6); chunk * 64u < total_paths;
+         chunk += gridDim.x * waves_per_block) {
+        PathState ps;
+        PathRngDev g;
+        ps.path = chunk * 64u + lane;
+        uint32_t px, py, s;
+        if (!path_to_pixel(pp, ps.path, px, py, s)) continue;
+        gen_primary(pp, px, py, pp.sample_begin + s, ps, g);
+        n_paths++;
+        bool alive = true;
+        while (alive) {
+            float t;
+            int prim;
+            closest_hit<COUNT>(pp.scene, lds_nodes, ps.o, ps.d, t, prim, wc);
+            n_rays++;
+            alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
+        }
+        pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+    }
+    unsigned long long r = n_rays, p = n_paths, a = wc.node_visits, b = wc.aabb_hits, c = wc.prim_tests;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        p += __shfl_down(p, off);
+        if (COUNT) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+            c += __shfl_down(c, off);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&pp.desc->rays, r);
+        atomicAdd(&pp.desc->paths, p);
+        if (COUNT) {
+            atomicAdd(&pp.desc->node_visits, a);
+            atomicAdd(&pp.desc->aabb_hits, b);
+            atomicAdd(&pp.desc->prim_tests, c);
+        }
+    }
+}
+
+// sum[pixel] += sum over the pass's samples (in sample order) of the clamped per-sample colour
+__global__ void k_resolve_sum(PassParams pp, float4* sum, uint32_t n_local_tiles) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_local_tiles * 64u) return;
+    uint32_t tl = i >> 6, lane = i & 63u;
+    uint32_t px, py, s0;
+    if (!path_to_pixel(pp, (tl * pp.S) * 64u + lane, px, py, s0)) return;
+    float4 acc = sum[py * pp.width + px];
+    for (uint32_t s = 0; s < pp.S; ++s) {
+        float4 v = pp.slots[(tl * pp.S + s) * 64u + lane];
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+    }
+    sum[py * pp.width + px] = acc;
+}
+
+// Fragment.metal:23-27,62-69 — running mean with the frameCount+1 weight and the clamp.
+__global__ void k_resolve_frame(PassParams pp, const float4* last, float4* cur, uint32_t n_local_tiles,
+                                unsigned long long frameCount) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_local_tiles * 64u) return;
+    uint32_t tl = i >> 6, lane = i & 63u;
+    uint32_t px, py, s0;
+    if (!path_to_pixel(pp, tl * 64u + lane, px, py, s0)) return;
+    float4 c = pp.slots[tl * 64u + lane];
+    float4 l = make_float4(0, 0, 0, 0);
+    if (frameCount != 0) l = last[py * pp.width + px];
+    unsigned long long fc = frameCount + 1ull;
+    float w = (float)(fc - 1ull), fcf = (float)fc;
+    float4 o;
+    o.x = clamp01((c.x + l.x * w) / fcf);
+    o.y = clamp01((c.y + l.y * w) / fcf);
+    o.z = clamp01((c.z + l.z * w) / fcf);
+    o.w = clamp01((c.w + l.w * w) / fcf);
+    cur[py * pp.width + px] = o;
+}
+
+// unit-test kernels ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_trace_rays(SceneDev sc, const float* o, const float* d, uint32_t n,
+                                                     float* t_out, int* prim_out, float* n_out, int* front_out) {
+    extern __shared__ float4 lds_nodes[];
+    stage_nodes(sc, lds_nodes);
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 ro = f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    float t;
+    int prim;
+    WorkCount wc = {0, 0, 0};
+    closest_hit<false>(sc, lds_nodes, ro, rd, t, prim, wc);
+    t_out[i] = t;
+    if (prim >= 0) {
+        HitInfo h = finish_hit(sc, ro, rd, t, prim);
+        prim_out[i] = h.orig_id;
+        n_out[3 * i] = h.normal.x;
+        n_out[3 * i + 1] = h.normal.y;
+        n_out[3 * i + 2] = h.normal.z;
+        front_out[i] = h.front ? 1 : 0;
+    } else {
+        prim_out[i] = -1;
+        n_out[3 * i] = n_out[3 * i + 1] = n_out[3 * i + 2] = 0.0f;
+        front_out[i] = 0;
+    }
+}
+__global__ void k_kat_pcg(const uint32_t* s, uint32_t n, uint32_t* h, float* f) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        h[i] = pcg_hash(s[i]);
+        f[i] = pcg_float(s[i]);
+    }
+}
+__global__ void k_kat_philox(const uint32_t* c, const uint32_t* k, uint32_t n, uint32_t* o) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        U4 r = philox4x32_10(c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3], k[2 * i], k[2 * i + 1]);
+        o[4 * i] = r.x;
+        o[4 * i + 1] = r.y;
+        o[4 * i + 2] = r.z;
+        o[4 * i + 3] = r.w;
+    }
+}
+__global__ void k_kat_sincos(const float* u, uint32_t n, float* s, float* c) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincos_2pi(u[i], s[i], c[i]);
+}
+
+// =====================================================================================================
+// host side of the C ABI
+// =====================================================================================================
+struct mpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string err;
+    // scene
+    float4* d_nodes = nullptr;
+    float4* d_prims = nullptr;
+    float4* d_mats = nullptr;
+    uint32_t n_nodes = 0, n_prims = 0, n_mats = 0, n_lds_nodes = 0;
+    bool have_scene = false;
+    // uniforms / size
+    mpt_uniforms u;
+    bool have_uniforms = false;
+    uint32_t W = 0, H = 0;
+    float4* d_accum[2] = {nullptr, nullptr};
+    int cur_target = 0;
+    float4* d_sum_own = nullptr;
+    float4* d_sum = nullptr;
+    // literal RNG seeds
+    uint32_t* d_pixel_seed = nullptr;
+    float seed_rs[3] = {NAN, NAN, NAN};
+    uint32_t seed_W = 0, seed_H = 0;
+    // pass workspace
+    QueueDev q[2] = {};
+    uint32_t shard_cap = 0;
+    float4* d_slots = nullptr;
+    uint64_t slots_cap = 0;
+    PassDesc* d_desc = nullptr;
+    uint32_t* h_done = nullptr;  // pinned, device-visible
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    // launch geometry
+    int wg_size = 1024;
+    int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
+    size_t lds_budget = 60 * 1024;
+    mpt_stats stats = {};
+};
+
+#define MPT_LDS_EXTRA 256  // iteration descriptor copy behind the node image
+
+#define HIPCHK(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return MPT_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+static int fail(mpt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" const char* mpt_status_string(int s) {
+    switch (s) {
+        case MPT_OK: return "ok";
+        case MPT_ERR_INVALID_ARG: return "invalid argument";
+        case MPT_ERR_NO_DEVICE: return "no HIP device";
+        case MPT_ERR_HIP: return "HIP runtime error";
+        case MPT_ERR_BAD_SCENE: return "malformed scene arrays";
+        case MPT_ERR_NOT_READY: return "scene, uniforms or size not set";
+        case MPT_ERR_OVERFLOW: return "ray queue overflow";
+    }
+    return "unknown status";
+}
+extern "C" const char* mpt_last_error(const mpt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
+    if (!out) return MPT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MPT_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return MPT_ERR_NO_DEVICE;
+    mpt_ctx* ctx = new mpt_ctx();
+    ctx->device = device_ordinal;
+    auto bail = [&](int code) {
+        delete ctx;
+        return code;
+    };
+    if (hipSetDevice(device_ordinal) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipGetDeviceProperties(&ctx->prop, device_ordinal) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipMalloc(&ctx->d_desc, sizeof(PassDesc)) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipMemset(ctx->d_desc, 0, sizeof(PassDesc)) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipHostMalloc((void**)&ctx->h_done, 64, hipHostMallocMapped) != hipSuccess) return bail(MPT_ERR_HIP);
+    *ctx->h_done = 0;
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) return bail(MPT_ERR_HIP);
+    const char* e;
+    if ((e = getenv("MPT_WG_SIZE"))) ctx->wg_size = atoi(e);
+    if ((e = getenv("MPT_WGS_PER_CU"))) ctx->wgs_per_cu = atoi(e);
+    if ((e = getenv("MPT_LDS_BYTES"))) ctx->lds_budget = (size_t)atol(e);
+    if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 1024;
+    if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
+    // allow the full 160 KiB of dynamic LDS
+    hipFuncSetAttribute((const void*)k_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_megakernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_megakernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = ctx;
+    return MPT_OK;
+}
+
+static void free_queues(mpt_ctx* ctx) {
+    for (int i = 0; i < 2; ++i) {
+        hipFree(ctx->q[i].od);
+        hipFree(ctx->q[i].dt);
+        hipFree(ctx->q[i].tl);
+        hipFree(ctx->q[i].ia);
+        ctx->q[i] = QueueDev{};
+    }
+    ctx->shard_cap = 0;
+}
+
+extern "C" int mpt_destroy(mpt_ctx* ctx) {
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->d_nodes);
+    hipFree(ctx->d_prims);
+    hipFree(ctx->d_mats);
+    hipFree(ctx->d_accum[0]);
+    hipFree(ctx->d_accum[1]);
+    hipFree(ctx->d_sum_own);
+    hipFree(ctx->d_pixel_seed);
+    hipFree(ctx->d_slots);
+    hipFree(ctx->d_desc);
+    free_queues(ctx);
+    hipHostFree(ctx->h_done);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    for (auto e : ctx->ev_pool) hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MPT_OK;
+}
+
+// ---- scene upload: reference arrays -> threaded, breadth-first, leaf-ordered device layout ----------------
+namespace {
+struct HostNode {
+    float bmin[3], bmax[3];
+    int leftFirst, count;
+};
+static inline int bits_to_int(float f) {
+    int i;
+    memcpy(&i, &f, 4);
+    return i;
+}
+static inline float int_to_bits(int i) {
+    float f;
+    memcpy(&f, &i, 4);
+    return f;
+}
+}  // namespace
+
+extern "C" int mpt_upload_scene(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims,
+                                const float* mats, const int32_t* prim_idx, uint64_t n_prims) {
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    if (!bvh || !prims || !mats || !prim_idx || n_nodes == 0 || n_prims == 0)
+        return fail(ctx, MPT_ERR_INVALID_ARG, "null or empty scene array");
+    if (n_nodes >= (1ull << 30) || n_prims >= (1ull << 27))
+        return fail(ctx, MPT_ERR_BAD_SCENE, "scene too large for the 27-bit leaf encoding");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t N = (uint32_t)n_nodes, P = (uint32_t)n_prims;
+
+    // 1. walk the reference tree in ITS visit order (root; right subtree; left subtree —
+    //    PathTracing.h:188-193 pushes left then right, so right pops first) and record the order.
+    std::vector<uint32_t> order;   // visit position -> reference node
+    std::vector<uint32_t> sub_end; // visit position -> visit position just past its subtree
+    order.reserve(N);
+    std::vector<uint8_t> seen(N, 0);
+    {
+        // iterative DFS with explicit post-processing for subtree ends
+        struct Fr {
+            uint32_t node, pos;
+            int stage;
+        };
+        std::vector<Fr> st;
+        st.push_back({0u, 0u, 0});
+        sub_end.assign(N, 0);
+        while (!st.empty()) {
+            Fr& f = st.back();
+            if (f.stage == 0) {
+                if (f.node >= N || seen[f.node]) return fail(ctx, MPT_ERR_BAD_SCENE, "BVH is not a tree (cycle or index out of range)");
+                seen[f.node] = 1;
+                f.pos = (uint32_t)order.size();
+                order.push_back(f.node);
+                int count = bits_to_int(bvh[8 * (size_t)f.node + 7]);
+                if (count > 0) {
+                    int first = bits_to_int(bvh[8 * (size_t)f.node + 3]);
+                    if (first < 0 || (uint64_t)first + (uint64_t)count > n_prims)
+                        return fail(ctx, MPT_ERR_BAD_SCENE, "leaf primitive range out of bounds");
+                    sub_end[f.pos] = f.pos + 1;
+                    st.pop_back();
+                } else {
+                    f.stage = 1;
+                    uint32_t right = (uint32_t)(-(long long)count);
+                    if (count == 0) return fail(ctx, MPT_ERR_BAD_SCENE, "internal node with right child 0");
+                    st.push_back({right, 0u, 0});
+                }
+            } else if (f.stage == 1) {
+                f.stage = 2;
+                int left = bits_to_int(bvh[8 * (size_t)f.node + 3]);
+                if (left < 0) return fail(ctx, MPT_ERR_BAD_SCENE, "negative left child");
+                st.push_back({(uint32_t)left, 0u, 0});
+            } else {
+                sub_end[f.pos] = (uint32_t)order.size();
+                st.pop_back();
+            }
+        }
+    }
+    const uint32_t NV = (uint32_t)order.size();  // reachable nodes
+
+    // 2. leaves: gather primitives into leaf order; split leaves of more than 16 primitives into a chain.
+    //    Device node list in VISIT order first (dn), then permuted breadth-first.
+    struct DNode {
+        float bmin[3], bmax[3];
+        bool leaf;
+        uint32_t first, count;   // leaf
+        uint32_t hit, miss;      // links as indices into dn (visit order); N_total = end
+    };
+    std::vector<DNode> dn;
+    dn.reserve(NV + 16);
+    std::vector<uint32_t> pos_to_dn(NV + 1, 0);  // visit position -> dn index of its (first) node
+    std::vector<float> dprims;
+    dprims.reserve((size_t)P * 12);
+    std::vector<float> mat_table;
+    std::map<std::vector<uint32_t>, uint32_t> mat_lookup;
+    auto mat_index = [&](uint32_t pid) -> uint32_t {
+        std::vector<uint32_t> key(8);
+        memcpy(key.data(), mats + 8 * (size_t)pid, 32);
+        auto it = mat_lookup.find(key);
+        if (it != mat_lookup.end()) return it->second;
+        uint32_t id = (uint32_t)(mat_table.size() / 8);
+        mat_table.insert(mat_table.end(), mats + 8 * (size_t)pid, mats + 8 * (size_t)pid + 8);
+        mat_lookup.emplace(std::move(key), id);
+        return id;
+    };
+    // first pass: create dn entries; a long leaf becomes ceil(count/16) chained nodes
+    for (uint32_t pos = 0; pos < NV; ++pos) {
+        const float* n = bvh + 8 * (size_t)order[pos];
+        int count = bits_to_int(n[7]);
+        pos_to_dn[pos] = (uint32_t)dn.size();
+        DNode d;
+        memcpy(d.bmin, n, 12);
+        memcpy(d.bmax, n + 4, 12);
+        d.hit = d.miss = 0;
+        if (count > 0) {
+            int first = bits_to_int(n[3]);
+            d.leaf = true;
+            for (int k0 = 0; k0 < count; k0 += 16) {
+                d.first = (uint32_t)(dprims.size() / 12);
+                d.count = (uint32_t)std::min(16, count - k0);
+                for (uint32_t k = 0; k < d.count; ++k) {
+                    int32_t pid = prim_idx[first + k0 + (int)k];
+                    if (pid < 0 || (uint64_t)pid >= n_prims) return fail(ctx, MPT_ERR_BAD_SCENE, "primitive index out of range");
+                    const float* p = prims + 12 * (size_t)pid;
+                    float rec[12];
+                    int type = (int)p[3];
+                    uint32_t m = mat_index((uint32_t)pid);
+                    if (type == 1) {  // triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (PathTracing.h:149-150)
+                        rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2]; rec[3] = 1.0f;
+                        rec[4] = p[4] - p[0]; rec[5] = p[5] - p[1]; rec[6] = p[6] - p[2];
+                        rec[8] = p[8] - p[0]; rec[9] = p[9] - p[1]; rec[10] = p[10] - p[2];
+                    } else {
+                        rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2]; rec[3] = p[3];
+                        rec[4] = p[4]; rec[5] = 0; rec[6] = 0;
+                        rec[8] = 0; rec[9] = 0; rec[10] = 0;
+                    }
+                    rec[7] = int_to_bits((int)m);
+                    rec[11] = int_to_bits(pid);
+                    dprims.insert(dprims.end(), rec, rec + 12);
+                }
+                dn.push_back(d);
+            }
+        } else {
+            d.leaf = false;
+            d.first = d.count = 0;
+            dn.push_back(d);
+        }
+    }
+    pos_to_dn[NV] = (uint32_t)dn.size();
+    const uint32_t ND = (uint32_t)dn.size();
+    // second pass: links.  In visit order the node after position pos is pos+1; a missed internal node
+    // skips to sub_end[pos].
+    for (uint32_t pos = 0; pos < NV; ++pos) {
+        uint32_t a = pos_to_dn[pos], b = pos_to_dn[pos + 1];
+        if (dn[a].leaf) {
+            for (uint32_t k = a; k < b; ++k) dn[k].hit = dn[k].miss = k + 1;  // chain, then the next position
+        } else {
+            dn[a].hit = a + 1;
+            dn[a].miss = pos_to_dn[sub_end[pos]];
+        }
+    }
+    // 3. breadth-first permutation (top of the tree first -> LDS).  Depth of a dn node = depth in the tree.
+    std::vector<uint32_t> depth(ND, 0);
+    {
+        // depth by walking positions: children of internal at pos are pos+1 (right) and sub_end[pos+1] (left)
+        std::vector<uint32_t> pdepth(NV, 0);
+        for (uint32_t pos = 0; pos < NV; ++pos) {
+            uint32_t a = pos_to_dn[pos];
+            if (!dn[a].leaf) {
+                uint32_t r = pos + 1;
+                if (r < NV) {
+                    pdepth[r] = pdepth[pos] + 1;
+                    uint32_t l = sub_end[r];
+                    if (l < NV && l < sub_end[pos]) pdepth[l] = pdepth[pos] + 1;
+                }
+            }
+            for (uint32_t k = a; k < pos_to_dn[pos + 1]; ++k) depth[k] = pdepth[pos];
+        }
+    }
+    std::vector<uint32_t> perm(ND);  // new index -> dn index
+    for (uint32_t i = 0; i < ND; ++i) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return depth[a] < depth[b]; });
+    // the root must stay at index 0 (depth 0, unique) — guaranteed by the stable sort
+    std::vector<uint32_t> inv(ND + 1);
+    for (uint32_t i = 0; i < ND; ++i) inv[perm[i]] = i;
+    inv[ND] = ND;  // terminator
+    std::vector<float> dnodes((size_t)ND * 8);
+    for (uint32_t i = 0; i < ND; ++i) {
+        const DNode& d = dn[perm[i]];
+        float* o = dnodes.data() + 8 * (size_t)i;
+        memcpy(o, d.bmin, 12);
+        memcpy(o + 4, d.bmax, 12);
+        if (d.leaf) {
+            o[3] = int_to_bits((int)inv[d.hit]);
+            o[7] = int_to_bits(-(int)(d.first * 16u + (d.count - 1u)) - 1);
+        } else {
+            o[3] = int_to_bits((int)inv[d.hit]);
+            o[7] = int_to_bits((int)inv[d.miss]);
+        }
+    }
+
+    hipFree(ctx->d_nodes);
+    hipFree(ctx->d_prims);
+    hipFree(ctx->d_mats);
+    ctx->d_nodes = ctx->d_prims = ctx->d_mats = nullptr;
+    ctx->have_scene = false;
+    HIPCHK(hipMalloc(&ctx->d_nodes, dnodes.size() * 4));
+    HIPCHK(hipMalloc(&ctx->d_prims, std::max<size_t>(dprims.size(), 12) * 4));
+    HIPCHK(hipMalloc(&ctx->d_mats, std::max<size_t>(mat_table.size(), 8) * 4));
+    HIPCHK(hipMemcpy(ctx->d_nodes, dnodes.data(), dnodes.size() * 4, hipMemcpyHostToDevice));
+    if (!dprims.empty()) HIPCHK(hipMemcpy(ctx->d_prims, dprims.data(), dprims.size() * 4, hipMemcpyHostToDevice));
+    if (!mat_table.empty()) HIPCHK(hipMemcpy(ctx->d_mats, mat_table.data(), mat_table.size() * 4, hipMemcpyHostToDevice));
+    ctx->n_nodes = ND;
+    ctx->n_prims = (uint32_t)(dprims.size() / 12);
+    ctx->n_mats = (uint32_t)(mat_table.size() / 8);
+    ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ND, ctx->lds_budget / 32);
+    ctx->have_scene = true;
+    return MPT_OK;
+}
+
+extern "C" int mpt_set_uniforms(mpt_ctx* ctx, const mpt_uniforms* u) {
+    if (!ctx || !u) return MPT_ERR_INVALID_ARG;
+    ctx->u = *u;
+    ctx->have_uniforms = true;
+    return MPT_OK;
+}
+
+extern "C" int mpt_resize(mpt_ctx* ctx, uint32_t width, uint32_t height) {
+    if (!ctx || width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 31))
+        return fail(ctx, MPT_ERR_INVALID_ARG, "bad size");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 2; ++i) {
+        hipFree(ctx->d_accum[i]);
+        ctx->d_accum[i] = nullptr;
+    }
+    hipFree(ctx->d_sum_own);
+    ctx->d_sum_own = nullptr;
+    size_t bytes = (size_t)width * height * 16;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipMalloc(&ctx->d_accum[i], bytes));
+        HIPCHK(hipMemset(ctx->d_accum[i], 0, bytes));
+    }
+    HIPCHK(hipMalloc(&ctx->d_sum_own, bytes));
+    HIPCHK(hipMemset(ctx->d_sum_own, 0, bytes));
+    ctx->d_sum = ctx->d_sum_own;
+    ctx->W = width;
+    ctx->H = height;
+    ctx->cur_target = 0;
+    return MPT_OK;
+}
+
+extern "C" int mpt_sum_buffer(mpt_ctx* ctx, void** p, uint64_t* bytes) {
+    if (!ctx || !p) return MPT_ERR_INVALID_ARG;
+    if (!ctx->d_sum) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
+    *p = ctx->d_sum;
+    if (bytes) *bytes = (uint64_t)ctx->W * ctx->H * 16;
+    return MPT_OK;
+}
+extern "C" int mpt_set_sum_buffer(mpt_ctx* ctx, void* p) {
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    ctx->d_sum = p ? (float4*)p : ctx->d_sum_own;
+    return MPT_OK;
+}
+extern "C" int mpt_clear_sum(mpt_ctx* ctx) {
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    if (!ctx->d_sum) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(ctx->d_sum, 0, (size_t)ctx->W * ctx->H * 16, ctx->stream));
+    return MPT_OK;
+}
+extern "C" void* mpt_stream(mpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int mpt_synchronize(mpt_ctx* ctx) {
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MPT_OK;
+}
+extern "C" int mpt_read_frame(mpt_ctx* ctx, float* out) {
+    if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+    if (!ctx->d_accum[0]) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(out, ctx->d_accum[ctx->cur_target], (size_t)ctx->W * ctx->H * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MPT_OK;
+}
+extern "C" int mpt_read_sum(mpt_ctx* ctx, float* out) {
+    if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+    if (!ctx->d_sum) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(out, ctx->d_sum, (size_t)ctx->W * ctx->H * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MPT_OK;
+}
+extern "C" int mpt_get_stats(mpt_ctx* ctx, mpt_stats* out) {
+    if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+    *out = ctx->stats;
+    return MPT_OK;
+}
+extern "C" int mpt_reset_stats(mpt_ctx* ctx) {
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    ctx->stats = mpt_stats{};
+    return MPT_OK;
+}
+
+// ---- pass machinery -------------------------------------------------------------------------------------------
+static SceneDev scene_dev(const mpt_ctx* ctx) {
+    SceneDev s;
+    s.nodes = ctx->d_nodes;
+    s.prims = ctx->d_prims;
+    s.mats = ctx->d_mats;
+    s.n_nodes = ctx->n_nodes;
+    s.n_lds_nodes = ctx->n_lds_nodes;
+    s.n_prims = ctx->n_prims;
+    s.n_mats = ctx->n_mats;
+    return s;
+}
+
+// Fragment.metal:29 + Random.h:32-35: per-pixel u32 seed of the literal RNG.  The float sin-hash is
+// chaotic in the last ulp of sin(), so it is evaluated once on the host with the
+// C library's sinf and uploaded; everything downstream is integer hashing on the device.
+static int ensure_pixel_seeds(mpt_ctx* ctx) {
+    const float* rs = ctx->u.randomSeed;
+    if (ctx->d_pixel_seed && ctx->seed_W == ctx->W && ctx->seed_H == ctx->H &&
+        memcmp(ctx->seed_rs, rs, 12) == 0)
+        return MPT_OK;
+    std::vector<uint32_t> seeds((size_t)ctx->W * ctx->H);
+    const float W = ctx->u.screenSize[0], H = ctx->u.screenSize[1];
+    for (uint32_t y = 0; y < ctx->H; ++y)
+        for (uint32_t x = 0; x < ctx->W; ++x) {
+            float uvx = ((float)x + 0.5f) / W, uvy = ((float)y + 0.5f) / H;
+            float v = sinf(uvx * rs[0] + uvy * rs[1]) * rs[2];
+            v = v - floorf(v);
+            seeds[(size_t)y * ctx->W + x] = (uint32_t)(v * 4294967296.0f);
+        }
+    hipFree(ctx->d_pixel_seed);
+    ctx->d_pixel_seed = nullptr;
+    HIPCHK(hipMalloc(&ctx->d_pixel_seed, seeds.size() * 4));
+    HIPCHK(hipMemcpy(ctx->d_pixel_seed, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice));
+    memcpy(ctx->seed_rs, rs, 12);
+    ctx->seed_W = ctx->W;
+    ctx->seed_H = ctx->H;
+    return MPT_OK;
+}
+
+static int ensure_workspace(mpt_ctx* ctx, uint32_t slots_items, uint64_t pass_paths) {
+    uint32_t cap = ((slots_items + MPT_NSHARD - 1) / MPT_NSHARD + 2) * 64u;
+    if (cap > ctx->shard_cap) {
+        free_queues(ctx);
+        size_t n = (size_t)cap * MPT_NSHARD;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipMalloc(&ctx->q[i].od, n * 16));
+            HIPCHK(hipMalloc(&ctx->q[i].dt, n * 16));
+            HIPCHK(hipMalloc(&ctx->q[i].tl, n * 16));
+            HIPCHK(hipMalloc(&ctx->q[i].ia, n * 8));
+        }
+        ctx->shard_cap = cap;
+    }
+    if (pass_paths > ctx->slots_cap) {
+        hipFree(ctx->d_slots);
+        ctx->d_slots = nullptr;
+        ctx->slots_cap = 0;
+        HIPCHK(hipMalloc(&ctx->d_slots, pass_paths * 16));
+        ctx->slots_cap = pass_paths;
+    }
+    return MPT_OK;
+}
+
+static int check_ready(mpt_ctx* ctx, const mpt_render_params* p) {
+    if (!ctx || !p) return MPT_ERR_INVALID_ARG;
+    if (!ctx->have_scene || !ctx->have_uniforms || !ctx->W) return fail(ctx, MPT_ERR_NOT_READY, "scene, uniforms or size not set");
+    if ((uint32_t)ctx->u.screenSize[0] != ctx->W || (uint32_t)ctx->u.screenSize[1] != ctx->H)
+        return fail(ctx, MPT_ERR_INVALID_ARG, "uniforms.screenSize does not match mpt_resize");
+    if (p->rng_mode < 0 || p->rng_mode > 1 || p->bsdf_mode < 0 || p->bsdf_mode > 1 || p->max_depth < 1 ||
+        p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 1 || p->shard_count < 1 || p->shard_rank < 0 ||
+        p->shard_rank >= p->shard_count)
+        return fail(ctx, MPT_ERR_INVALID_ARG, "bad render params");
+    return MPT_OK;
+}
+
+static inline bool count_flag(const mpt_render_params* p) { return (p->flags & MPT_FLAG_COUNT_WORK) != 0; }
+
+// Runs one pass of S samples/pixel over this rank's tiles; leaves the per-path results in d_slots.
+static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_begin, uint32_t S, PassParams& pp,
+                    uint32_t& n_local_tiles, bool time_kernels) {
+    const uint32_t tiles_x = (ctx->W + 7) / 8, tiles_y = (ctx->H + 7) / 8, tiles = tiles_x * tiles_y;
+    const uint32_t nr = (uint32_t)p->shard_count, rk = (uint32_t)p->shard_rank;
+    n_local_tiles = tiles > rk ? (tiles - rk + nr - 1) / nr : 0;
+    const uint64_t pass_paths = (uint64_t)n_local_tiles * S * 64ull;
+    if (pass_paths >= (1ull << 27)) return fail(ctx, MPT_ERR_INVALID_ARG, "pass too large (internal)");
+    uint32_t slots = p->slots_per_iter ? p->slots_per_iter : (16u << 20);
+    uint32_t slots_items = std::max<uint32_t>(64, (slots + 63) / 64);
+    if ((uint64_t)slots_items * 64 > pass_paths + 64) slots_items = (uint32_t)((pass_paths + 63) / 64);
+    if (slots_items < 8) slots_items = 8;
+    int rc = ensure_workspace(ctx, slots_items, std::max<uint64_t>(pass_paths, 64));
+    if (rc) return rc;
+    if (p->rng_mode == MPT_RNG_LITERAL && (rc = ensure_pixel_seeds(ctx))) return rc;
+
+    pp.scene = scene_dev(ctx);
+    pp.q[0] = ctx->q[0];
+    pp.q[1] = ctx->q[1];
+    pp.shard_cap = ctx->shard_cap;
+    pp.desc = ctx->d_desc;
+    pp.slots = ctx->d_slots;
+    pp.pixel_seed = ctx->d_pixel_seed;
+    const mpt_uniforms& u = ctx->u;
+    pp.cam = F3{u.cameraPosition[0], u.cameraPosition[1], u.cameraPosition[2]};
+    pp.first = F3{u.firstPixelPosition[0], u.firstPixelPosition[1], u.firstPixelPosition[2]};
+    pp.vu = F3{u.viewportU[0], u.viewportU[1], u.viewportU[2]};
+    pp.vv = F3{u.viewportV[0], u.viewportV[1], u.viewportV[2]};
+    pp.W = u.screenSize[0];
+    pp.H = u.screenSize[1];
+    pp.width = ctx->W;
+    pp.height = ctx->H;
+    pp.tiles_x = tiles_x;
+    pp.S = S;
+    pp.sample_begin = sample_begin;
+    pp.rank = rk;
+    pp.nranks = nr;
+    pp.sp.rng_mode = p->rng_mode;
+    pp.sp.bsdf_mode = p->bsdf_mode;
+    pp.sp.max_depth = p->max_depth;
+    pp.sp.seed_lo = p->seed_lo;
+    pp.sp.seed_hi = p->seed_hi;
+    pp.sp.primitive_count = (uint32_t)std::min<uint64_t>(u.primitiveCount, 0xFFFFFFFFull);
+    uint32_t* dev_done = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void**)&dev_done, ctx->h_done, 0));
+    pp.host_done = dev_done;
+    if (pass_paths == 0) return MPT_OK;
+
+    const bool count = count_flag(p);
+    const size_t lds = (size_t)ctx->n_lds_nodes * 32 + MPT_LDS_EXTRA;
+    int per_cu = 0;
+    if (p->pipeline == MPT_PIPE_MEGAKERNEL) {
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, count_flag(p) ? (const void*)k_megakernel<true> : (const void*)k_megakernel<false>, ctx->wg_size, lds));
+    } else {
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, count_flag(p) ? (const void*)k_step<true> : (const void*)k_step<false>, ctx->wg_size, lds));
+    }
+    if (per_cu < 1) return fail(ctx, MPT_ERR_HIP, "kernel does not fit on a CU");
+    if (ctx->wgs_per_cu > 0 && per_cu > ctx->wgs_per_cu) per_cu = ctx->wgs_per_cu;
+    const int grid = ctx->prop.multiProcessorCount * per_cu;
+    hipStream_t st = ctx->stream;
+    *ctx->h_done = 0;
+    hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, ctx->d_desc, (uint32_t)pass_paths, slots_items,
+                       (volatile uint32_t*)dev_done);
+    if (p->pipeline == MPT_PIPE_MEGAKERNEL) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (time_kernels) {
+            HIPCHK(hipEventCreate(&e0));
+            HIPCHK(hipEventCreate(&e1));
+            HIPCHK(hipEventRecord(e0, st));
+        }
+        if (count)
+            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(ctx->wg_size), lds, st, pp);
+        else
+            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(ctx->wg_size), lds, st, pp);
+        HIPCHK(hipGetLastError());
+        if (time_kernels) {
+            HIPCHK(hipEventRecord(e1, st));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            ctx->stats.trace_kernel_ms += ms;
+            ctx->stats.trace_launches += 1;
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+        ctx->stats.iterations += 1;
+        return MPT_OK;
+    }
+    // wavefront: enqueue iterations in batches; the device publishes `done` to pinned host memory
+    std::vector<hipEvent_t>& pool = ctx->ev_pool;
+    size_t ev_used = 0;
+    auto get_event = [&]() -> hipEvent_t {
+        if (ev_used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[ev_used++];
+    };
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    uint32_t parity = 0;
+    uint64_t launched = 0;
+    const uint64_t est = (pass_paths * 2) / ((uint64_t)slots_items * 64) + (uint64_t)p->max_depth + 2;
+    const uint64_t hard_cap = est * 8 + 64;
+    const int batch = 4;
+    for (;;) {
+        for (int b = 0; b < batch; ++b) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (time_kernels) {
+                e0 = get_event();
+                e1 = get_event();
+                if (!e0 || !e1) return fail(ctx, MPT_ERR_HIP, "hipEventCreate failed");
+                HIPCHK(hipEventRecord(e0, st));
+            }
+            if (count)
+                hipLaunchKernelGGL(k_step<true>, dim3(grid), dim3(ctx->wg_size), lds, st, pp, parity);
+            else
+                hipLaunchKernelGGL(k_step<false>, dim3(grid), dim3(ctx->wg_size), lds, st, pp, parity);
+            if (time_kernels) {
+                HIPCHK(hipEventRecord(e1, st));
+                timed.emplace_back(e0, e1);
+            }
+            hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->d_desc, (volatile uint32_t*)dev_done);
+            parity ^= 1u;
+            launched++;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        uint32_t flag = *(volatile uint32_t*)ctx->h_done;
+        if (flag & 2u) return fail(ctx, MPT_ERR_OVERFLOW, "ray queue overflow");
+        if (flag & 1u) break;
+        if (launched > hard_cap) return fail(ctx, MPT_ERR_HIP, "pass did not drain (internal)");
+    }
+    if (time_kernels) {
+        PassDesc hd;
+        HIPCHK(hipMemcpy(&hd, ctx->d_desc, sizeof hd, hipMemcpyDeviceToHost));
+        // only the iterations that had work count as launches of the dominant kernel
+        uint64_t real = hd.iterations;
+        for (size_t i = 0; i < timed.size() && i < real; ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, timed[i].first, timed[i].second));
+            ctx->stats.trace_kernel_ms += ms;
+        }
+        ctx->stats.trace_launches += real;
+    }
+    return MPT_OK;
+}
+
+static int collect_pass_stats(mpt_ctx* ctx) {
+    PassDesc hd;
+    HIPCHK(hipMemcpy(&hd, ctx->d_desc, sizeof hd, hipMemcpyDeviceToHost));
+    ctx->stats.paths += hd.paths;
+    ctx->stats.rays += hd.rays;
+    ctx->stats.node_visits += hd.node_visits;
+    ctx->stats.aabb_hits += hd.aabb_hits;
+    ctx->stats.prim_tests += hd.prim_tests;
+    ctx->stats.iterations += hd.iterations;
+    HIPCHK(hipMemsetAsync(&ctx->d_desc->paths, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(&ctx->d_desc->iterations, 0, 4, ctx->stream));
+    return MPT_OK;
+}
+
+extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
+    int rc = check_ready(ctx, p);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->stats.trace_kernel_ms = 0;
+    ctx->stats.trace_launches = 0;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    const uint32_t tiles = ((ctx->W + 7) / 8) * ((ctx->H + 7) / 8);
+    const uint32_t local_tiles = (tiles + p->shard_count - 1) / p->shard_count;
+    uint32_t s_max = (uint32_t)std::max<uint64_t>(1, ((1ull << 27) - 64) / ((uint64_t)std::max(1u, local_tiles) * 64ull));
+    if (s_max > 64) s_max = 64;
+    const char* e = getenv("MPT_PASS_SPP");
+    if (e && atoi(e) > 0) s_max = std::min<uint32_t>(s_max, (uint32_t)atoi(e));
+    uint32_t done = 0;
+    while (done < p->sample_count) {
+        uint32_t S = std::min(s_max, p->sample_count - done);
+        PassParams pp;
+        uint32_t nlt = 0;
+        rc = run_pass(ctx, p, p->sample_begin + done, S, pp, nlt, true);
+        if (rc) return rc;
+        if (nlt) {
+            uint32_t threads = nlt * 64u;
+            hipLaunchKernelGGL(k_resolve_sum, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, pp, ctx->d_sum, nlt);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if ((rc = collect_pass_stats(ctx))) return rc;
+        done += S;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->stats.total_ms = ms;
+    return MPT_OK;
+}
+
+extern "C" int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p) {
+    int rc = check_ready(ctx, p);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->cur_target ^= 1;  // std::swap(_accumulationTargets[0], [1]) — Renderer.cpp:278
+    PassParams pp;
+    uint32_t nlt = 0;
+    rc = run_pass(ctx, p, p->sample_begin, 1, pp, nlt, false);
+    if (rc) return rc;
+    if (nlt) {
+        uint32_t threads = nlt * 64u;
+        hipLaunchKernelGGL(k_resolve_frame, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, pp,
+                           (const float4*)ctx->d_accum[ctx->cur_target ^ 1], ctx->d_accum[ctx->cur_target], nlt,
+                           (unsigned long long)ctx->u.frameCount);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return collect_pass_stats(ctx);
+}
+
+// ---- unit-test entry points -----------------------------------------------------------------------------------
+extern "C" int mpt_trace_rays(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out,
+                              int32_t* prim_out, float* normal_out, int32_t* front_out) {
+    if (!ctx || !o || !d || !t_out || !prim_out || !normal_out || !front_out || n == 0 || n > (1ull << 30))
+        return fail(ctx, MPT_ERR_INVALID_ARG, "bad argument");
+    if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
+    HIPCHK(hipSetDevice(ctx->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr;
+    int *d_p = nullptr, *d_f = nullptr;
+    HIPCHK(hipMalloc(&d_o, n * 12));
+    HIPCHK(hipMalloc(&d_d, n * 12));
+    HIPCHK(hipMalloc(&d_t, n * 4));
+    HIPCHK(hipMalloc(&d_n, n * 12));
+    HIPCHK(hipMalloc(&d_p, n * 4));
+    HIPCHK(hipMalloc(&d_f, n * 4));
+    HIPCHK(hipMemcpy(d_o, o, n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_d, d, n * 12, hipMemcpyHostToDevice));
+    SceneDev sc = scene_dev(ctx);
+    hipLaunchKernelGGL(k_trace_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), (size_t)ctx->n_lds_nodes * 32 + MPT_LDS_EXTRA,
+                       ctx->stream, sc, (const float*)d_o, (const float*)d_d, (uint32_t)n, d_t, d_p, d_n, d_f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(t_out, d_t, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(prim_out, d_p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(normal_out, d_n, n * 12, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(front_out, d_f, n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_n); hipFree(d_p); hipFree(d_f);
+    return MPT_OK;
+}
+
+template <typename F>
+static int kat_run(mpt_ctx* ctx, const void* const* in, const size_t* in_bytes, int n_in, void* const* out,
+                   const size_t* out_bytes, int n_out, F launch) {
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<void*> di(n_in), dout(n_out);
+    for (int i = 0; i < n_in; ++i) {
+        HIPCHK(hipMalloc(&di[i], in_bytes[i]));
+        HIPCHK(hipMemcpy(di[i], in[i], in_bytes[i], hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < n_out; ++i) HIPCHK(hipMalloc(&dout[i], out_bytes[i]));
+    launch(di, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_out; ++i) HIPCHK(hipMemcpy(out[i], dout[i], out_bytes[i], hipMemcpyDeviceToHost));
+    for (auto p : di) hipFree(p);
+    for (auto p : dout) hipFree(p);
+    return MPT_OK;
+}
+
+extern "C" int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* h, float* f) {
+    if (!ctx || !seeds || !h || !f || n == 0 || n > (1u << 28)) return MPT_ERR_INVALID_ARG;
+    const void* in[] = {seeds};
+    size_t ib[] = {n * 4};
+    void* out[] = {h, f};
+    size_t ob[] = {n * 4, n * 4};
+    return kat_run(ctx, in, ib, 1, out, ob, 2, [&](std::vector<void*>& di, std::vector<void*>& dout) {
+        hipLaunchKernelGGL(k_kat_pcg, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)di[0], (uint32_t)n, (uint32_t*)dout[0], (float*)dout[1]);
+    });
+}
+extern "C" int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* c, const uint32_t* k, uint64_t n, uint32_t* o) {
+    if (!ctx || !c || !k || !o || n == 0 || n > (1u << 26)) return MPT_ERR_INVALID_ARG;
+    const void* in[] = {c, k};
+    size_t ib[] = {n * 16, n * 8};
+    void* out[] = {o};
+    size_t ob[] = {n * 16};
+    return kat_run(ctx, in, ib, 2, out, ob, 1, [&](std::vector<void*>& di, std::vector<void*>& dout) {
+        hipLaunchKernelGGL(k_kat_philox, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)di[0], (const uint32_t*)di[1], (uint32_t)n, (uint32_t*)dout[0]);
+    });
+}
+extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s, float* c) {
+    if (!ctx || !u || !s || !c || n == 0 || n > (1u << 28)) return MPT_ERR_INVALID_ARG;
+    const void* in[] = {u};
+    size_t ib[] = {n * 4};
+    void* out[] = {s, c};
+    size_t ob[] = {n * 4, n * 4};
+    return kat_run(ctx, in, ib, 1, out, ob, 2, [&](std::vector<void*>& di, std::vector<void*>& dout) {
+        hipLaunchKernelGGL(k_kat_sincos, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float*)di[0], (uint32_t)n, (float*)dout[0], (float*)dout[1]);
+    });
+}
