@@ -1,0 +1,77 @@
+/* mpt_host.h — C ABI of the HOST layer (libmpt_host.so): scene ingest, BVH build, buffer packing,
+ * camera/viewport maths, the Renderer frame protocol and image output.  Pure host C++ underneath
+ * (metalpathtracer_amd/csrc/host/); the Renderer entry points drive the GPU through include/mpt.h.
+ *
+ * Reference interfaces replaced (R/ = "MetalCpp Path Tracer/"):
+ *   mpt_scene_*        class Scene                      R/Scene/Scene.h:34-188
+ *   mpt_scene_load_xml SceneLoader::LoadSceneFromXML    R/Scene/SceneLoader.h:11, SceneLoader.cpp:75-133
+ *   mpt_camera_*       namespace Camera + recalculateViewport   R/Renderer/Camera.h:24-32, Renderer.cpp:153-182
+ *   mpt_renderer_*     class Renderer                   R/Renderer/Renderer.h:16-29
+ */
+#ifndef MPT_HOST_H
+#define MPT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mpt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpt_scene mpt_scene;
+typedef struct mpt_renderer mpt_renderer;
+
+enum { MPT_BVH_REFERENCE_SWEEP = 0, MPT_BVH_BINNED_CENTROID = 1 };
+enum { MPT_PRIM_SPHERE = 0, MPT_PRIM_TRIANGLE = 1 };
+
+/* Scene (R/Scene/Scene.h) */
+int mpt_scene_create(mpt_scene** out);
+int mpt_scene_destroy(mpt_scene* s);
+int mpt_scene_clear(mpt_scene* s);
+/* returns SceneLoader::Status (0 ok, 1 xml unreadable, 2 no <Scene>, 3 malformed, 4 mesh unreadable);
+ * what the reference would printf is copied (NUL-terminated, truncated) into log when log_cap > 0 */
+int mpt_scene_load_xml(mpt_scene* s, const char* xml_path, const char* asset_root, char* log, size_t log_cap);
+/* type: MPT_PRIM_*; sphere: d0 centre, d1[0] radius; triangle: three vertices; mat: albedo rgb, materialType,
+ * emission rgb, emissionPower */
+int mpt_scene_add_primitive(mpt_scene* s, int type, const float d0[3], const float d1[3], const float d2[3],
+                            const float mat[8]);
+int mpt_scene_build_bvh(mpt_scene* s, int mode);
+int mpt_scene_counts(const mpt_scene* s, uint64_t* prims, uint64_t* triangles, uint64_t* nodes, int32_t* depth);
+/* copies the four flat buffers: bvh 8 floats/node, prims 12 floats/prim, mats 8 floats/prim,
+ * prim_idx 1 int/prim; any pointer may be NULL to skip */
+int mpt_scene_copy_buffers(const mpt_scene* s, float* bvh, float* prims, float* mats, int32_t* prim_idx);
+
+/* Camera (R/Renderer/Camera.h:24-32) + viewport (R/Renderer/Renderer.cpp:153-182).  Writes cameraPosition,
+ * viewportU/V, firstPixelPosition and screenSize of *u; other fields untouched. */
+int mpt_camera_reset_values(float pos[3], float fwd[3], float up[3], float* vfov_deg);
+int mpt_camera_viewport(const float pos[3], const float fwd[3], const float up[3], float vfov_deg, float width,
+                        float height, mpt_uniforms* u);
+/* host PCG stream behind Renderer::updateUniforms' randomSeed (R/Renderer/Renderer.cpp:30-41) */
+float mpt_host_random_float(uint32_t* state);
+
+/* Renderer (R/Renderer/Renderer.h:16-29) — constructor order of Renderer.cpp:43-57 */
+int mpt_renderer_create(int device, const char* xml_path, const char* asset_root, mpt_renderer** out, char* err,
+                        size_t err_cap);
+int mpt_renderer_destroy(mpt_renderer* r);
+int mpt_renderer_drawable_size_will_change(mpt_renderer* r, uint32_t width, uint32_t height);
+int mpt_renderer_set_params(mpt_renderer* r, const mpt_render_params* p);
+int mpt_renderer_draw(mpt_renderer* r);                       /* updateUniforms + one frame              */
+int mpt_renderer_read_frame(mpt_renderer* r, float* rgba);    /* W*H*4 floats                            */
+int mpt_renderer_render_batch(mpt_renderer* r, uint32_t sample_begin, uint32_t sample_count);
+int mpt_renderer_read_sum(mpt_renderer* r, float* rgba);
+int mpt_renderer_clear_sum(mpt_renderer* r);
+int mpt_renderer_uniforms(mpt_renderer* r, mpt_uniforms* out);
+int mpt_renderer_stats(mpt_renderer* r, mpt_stats* out);
+mpt_ctx* mpt_renderer_context(mpt_renderer* r);
+mpt_scene* mpt_renderer_scene(mpt_renderer* r);               /* borrowed                                */
+
+/* Image output (the reference has none).  rgba: W*H*4 floats, top-left origin; value = rgba * scale. */
+int mpt_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height, float scale);
+int mpt_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height, float scale, float gamma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPT_HOST_H */

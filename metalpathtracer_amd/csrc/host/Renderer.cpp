@@ -1,0 +1,212 @@
+// Renderer.cpp — see Renderer.h.  Host-side frame protocol of the reference renderer
+// (R/Renderer/Renderer.cpp) expressed over the C ABI.
+#include "Renderer.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+#include "Camera.h"
+#include "SceneLoader.h"
+
+namespace MetalCppPathTracer {
+
+void Renderer::check(int status, const char* where) {
+    if (status == MPT_OK) return;
+    std::string msg = std::string(where) + ": " + mpt_status_string(status);
+    if (ctx_) msg += std::string(" (") + mpt_last_error(ctx_) + ")";
+    throw std::runtime_error(msg);
+}
+
+// host PCG stream of the reference (R/Renderer/Renderer.cpp:30-41)
+float Renderer::hostRandomFloat() {
+    const uint32_t state = hostSeed_ * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state);
+    hostSeed_ = (word >> 22u) ^ word;
+    return static_cast<float>(hostSeed_) / static_cast<float>(std::numeric_limits<uint32_t>::max());
+}
+
+Renderer::Renderer(int deviceOrdinal, const std::string& scenePath, const std::string& assetRoot)
+    : device_(deviceOrdinal), scene_(new Scene()), scenePath_(scenePath), assetRoot_(assetRoot) {
+    std::memset(&uniforms_, 0, sizeof uniforms_);
+    std::memset(&params_, 0, sizeof params_);
+    params_.rng_mode = MPT_RNG_LITERAL;  // what the reference's shader does
+    params_.bsdf_mode = MPT_BSDF_LAMBERT;
+    params_.max_depth = 32;              // R/Renderer/Shaders/PathTracing.h:216
+    params_.pipeline = MPT_PIPE_WAVEFRONT;
+    params_.sample_count = 1;
+    params_.seed_lo = 1;
+    params_.shard_count = 1;
+    int rc = mpt_create(deviceOrdinal, &ctx_);
+    if (rc != MPT_OK) {
+        delete scene_;
+        scene_ = nullptr;
+        throw std::runtime_error(std::string("mpt_create: ") + mpt_status_string(rc) +
+                                 " — a MI355X GPU is required, there is no CPU fallback");
+    }
+    Camera::reset();
+    Camera::screenSize = mpt::float2{1280.0f, 720.0f};  // R/Renderer/Renderer.cpp:48-49
+    if (!scenePath_.empty()) {
+        updateVisibleScene();
+        buildShaders();
+        buildBuffers();
+        buildTextures();
+        recalculateViewport();
+    }
+}
+
+Renderer::~Renderer() {
+    if (ctx_) mpt_destroy(ctx_);
+    delete scene_;
+}
+
+void Renderer::setScenePath(const std::string& xml, const std::string& assetRoot) {
+    scenePath_ = xml;
+    assetRoot_ = assetRoot;
+}
+
+void Renderer::updateVisibleScene() {
+    std::string log;
+    SceneLoader::Load(scenePath_, scene_, assetRoot_, &log);
+    std::fputs(log.c_str(), stdout);
+    std::printf("Scene loaded: %zu total primitives (%zu spheres, %zu triangles)\n", scene_->getPrimitiveCount(),
+                scene_->getPrimitiveCount() - scene_->getTriangleCount(), scene_->getTriangleCount());
+    scene_->buildBVH();
+    std::printf("BVH node count: %zu\n", scene_->getBVHNodeCount());
+    buildBuffers();
+}
+
+void Renderer::buildShaders() {
+    if (!ctx_) throw std::runtime_error("buildShaders: no device context");
+}
+
+void Renderer::buildBuffers() {
+    // The reference uploads BVH/index buffers in updateVisibleScene and primitive/material buffers here
+    // (R/Renderer/Renderer.cpp:127-146,199-215); the device layout needs all four at once, so one upload.
+    const size_t P = scene_->getPrimitiveCount();
+    sceneUploaded_ = false;
+    if (P == 0 || scene_->getBVHNodeCount() == 0) return;
+    mpt::float4* bvh = scene_->createBVHBuffer();
+    mpt::float4* prims = scene_->createTransformsBuffer();
+    mpt::float4* mats = scene_->createMaterialsBuffer();
+    int* idx = scene_->createPrimitiveIndexBuffer();
+    int rc = mpt_upload_scene(ctx_, reinterpret_cast<const float*>(bvh), scene_->getBVHNodeCount(),
+                              reinterpret_cast<const float*>(prims), reinterpret_cast<const float*>(mats), idx, P);
+    delete[] bvh;
+    delete[] prims;
+    delete[] mats;
+    delete[] idx;
+    check(rc, "mpt_upload_scene");
+    sceneUploaded_ = true;
+    // a fresh uniforms buffer is zero-filled (Metal zero-fills new buffers)
+    std::memset(&uniforms_, 0, sizeof uniforms_);
+}
+
+void Renderer::buildTextures() {
+    check(mpt_resize(ctx_, static_cast<uint32_t>(Camera::screenSize.x), static_cast<uint32_t>(Camera::screenSize.y)),
+          "mpt_resize");
+}
+
+void Renderer::recalculateViewport() {
+    const float aspect = Camera::screenSize.x / Camera::screenSize.y;
+    const float fovRad = Camera::verticalFov * (M_PI / 180.0f);
+    const float halfH = tanf(fovRad * 0.5f);
+    const float halfW = aspect * halfH;
+    const mpt::float3 w = mpt::normalize(-Camera::forward);
+    const mpt::float3 u = mpt::normalize(mpt::cross(Camera::up, w));
+    const mpt::float3 v = mpt::cross(w, u);
+    const mpt::float3 vu = u * (2.0f * halfW);
+    const mpt::float3 vv = (-v) * (2.0f * halfH);
+    const mpt::float3 first = Camera::position - w - (vu * 0.5f) - (vv * 0.5f);
+    auto put = [](float* dst, const mpt::float3& s) {
+        dst[0] = s.x;
+        dst[1] = s.y;
+        dst[2] = s.z;
+        dst[3] = 0.0f;
+    };
+    put(uniforms_.cameraPosition, Camera::position);
+    put(uniforms_.viewportU, vu);
+    put(uniforms_.viewportV, vv);
+    put(uniforms_.firstPixelPosition, first);
+    uniforms_.screenSize[0] = Camera::screenSize.x;
+    uniforms_.screenSize[1] = Camera::screenSize.y;
+    std::printf("viewportU: (%f, %f, %f)\n", vu.x, vu.y, vu.z);
+    std::printf("viewportV: (%f, %f, %f)\n", vv.x, vv.y, vv.z);
+    std::printf("firstPixel: (%f, %f, %f)\n", first.x, first.y, first.z);
+}
+
+bool Renderer::updateCamera() {
+    const bool changed = Camera::transformWithInputs();
+    if (changed) recalculateViewport();
+    return changed;
+}
+
+void Renderer::updateUniforms() {
+    if (updateCamera()) {
+        uniforms_.frameCount = 0;
+        uniforms_.randomSeed[0] = hostRandomFloat();
+        uniforms_.randomSeed[1] = hostRandomFloat();
+        uniforms_.randomSeed[2] = hostRandomFloat();
+    } else {
+        uniforms_.frameCount++;
+    }
+    uniforms_.primitiveCount = scene_->getPrimitiveCount();
+    uniforms_.triangleCount = scene_->getTriangleCount();
+    check(mpt_set_uniforms(ctx_, &uniforms_), "mpt_set_uniforms");
+}
+
+void Renderer::draw(OffscreenView* /*view*/) {
+    updateUniforms();
+    mpt_render_params p = params_;
+    p.sample_count = 1;
+    if (p.rng_mode == MPT_RNG_PHILOX) p.sample_begin = static_cast<uint32_t>(uniforms_.frameCount);
+    check(mpt_draw(ctx_, &p), "mpt_draw");  // swaps the accumulation targets, then launches
+}
+
+void Renderer::drawableSizeWillChange(OffscreenView* view, DrawableSize size) {
+    Camera::screenSize = mpt::float2{static_cast<float>(size.width), static_cast<float>(size.height)};
+    if (view) {
+        view->width = static_cast<uint32_t>(size.width);
+        view->height = static_cast<uint32_t>(size.height);
+    }
+    buildTextures();
+    recalculateViewport();
+}
+
+void Renderer::readFrame(OffscreenView* view) {
+    const uint32_t W = static_cast<uint32_t>(Camera::screenSize.x), H = static_cast<uint32_t>(Camera::screenSize.y);
+    view->width = W;
+    view->height = H;
+    view->rgba.resize(static_cast<size_t>(W) * H * 4);
+    check(mpt_read_frame(ctx_, view->rgba.data()), "mpt_read_frame");
+}
+
+int Renderer::renderBatch(uint32_t sampleBegin, uint32_t sampleCount) {
+    uniforms_.primitiveCount = scene_->getPrimitiveCount();
+    uniforms_.triangleCount = scene_->getTriangleCount();
+    check(mpt_set_uniforms(ctx_, &uniforms_), "mpt_set_uniforms");
+    mpt_render_params p = params_;
+    p.sample_begin = sampleBegin;
+    p.sample_count = sampleCount;
+    int rc = mpt_render(ctx_, &p);
+    check(rc, "mpt_render");
+    return rc;
+}
+
+void Renderer::readSum(std::vector<float>& rgba) {
+    const size_t n = static_cast<size_t>(Camera::screenSize.x) * static_cast<size_t>(Camera::screenSize.y) * 4;
+    rgba.resize(n);
+    check(mpt_read_sum(ctx_, rgba.data()), "mpt_read_sum");
+}
+
+void Renderer::clearSum() { check(mpt_clear_sum(ctx_), "mpt_clear_sum"); }
+
+mpt_stats Renderer::stats() {
+    mpt_stats s;
+    check(mpt_get_stats(ctx_, &s), "mpt_get_stats");
+    return s;
+}
+
+}  // namespace MetalCppPathTracer

@@ -46,9 +46,6 @@ struct PassDesc {
     uint32_t n_items;
     uint32_t regen_base;
     uint32_t range_end[MPT_NGROUP];
-    // atomics
-    uint32_t cursor[MPT_NGROUP];
-    uint32_t out_count[MPT_NSHARD];
     // pass state
     uint32_t next_path, total_paths;
     uint32_t slots_items;  // wavefront width in 64-slot items
@@ -56,8 +53,16 @@ struct PassDesc {
     unsigned long long paths, rays, node_visits, aabb_hits, prim_tests;
 };
 
+// Atomic counters live on lines of their own (MPT_CTR_STRIDE words apart): device-scope atomics are
+// executed at the memory side, and counters that share a line serialise there.
+#define MPT_CTR_STRIDE 1024u  // in uint32 words = 4 KiB
+#define MPT_CTR_CURSOR(g) ((g) * MPT_CTR_STRIDE)
+#define MPT_CTR_OUT(s) ((MPT_NGROUP + (s)) * MPT_CTR_STRIDE)
+#define MPT_CTR_WORDS ((MPT_NGROUP + MPT_NSHARD) * MPT_CTR_STRIDE)
+
 struct PassParams {
     SceneDev scene;
+    uint32_t* ctr;               // work cursors [NGROUP] and output counters [NSHARD], padded
     QueueDev q[2];
     uint32_t shard_cap;
     PassDesc* desc;
@@ -131,29 +136,38 @@ __device__ __forceinline__ void stage_nodes(const SceneDev& sc, float4* lds) {
     __syncthreads();
 }
 
-// wave-uniform work-item fetch from the per-group cursors (home group first, then steal)
+// Wave-uniform work fetch: a wave claims a run of consecutive 64-slot items from its home group's
+// cursor (then steals from the other groups).  The run length is guided — remaining / (2 * waves) clamped
+// to [1, 16] — so the bulk of an iteration costs few atomics and the tail stays fine-grained.
 // (every lane of the wave is active here, so readfirstlane returns lane 0's value as an SGPR)
-__device__ __forceinline__ uint32_t fetch_item(PassDesc* desc, const uint32_t* s_range_end, uint32_t home) {
-    uint32_t item = MPT_NONE;
+__device__ __forceinline__ void fetch_items(uint32_t* ctr, const uint32_t* s_range_end, uint32_t home,
+                                            uint32_t waves_per_group, uint32_t& first, uint32_t& last) {
+    uint32_t f = MPT_NONE, l = 0;
     if ((threadIdx.x & 63u) == 0) {
         for (uint32_t t = 0; t < MPT_NGROUP; ++t) {
             uint32_t g = (home + t) & (MPT_NGROUP - 1);
             uint32_t end = s_range_end[g];
-            if (__hip_atomic_load(&desc->cursor[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= end) continue;
-            uint32_t k = atomicAdd(&desc->cursor[g], 1u);
+            uint32_t cur = __hip_atomic_load(&ctr[MPT_CTR_CURSOR(g)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur >= end) continue;
+            uint32_t run = (end - cur) / (2u * waves_per_group);
+            run = run < 1u ? 1u : (run > 16u ? 16u : run);
+            uint32_t k = atomicAdd(&ctr[MPT_CTR_CURSOR(g)], run);
             if (k < end) {
-                item = k;
+                f = k;
+                l = (k + run < end) ? k + run : end;
                 break;
             }
         }
     }
-    return __builtin_amdgcn_readfirstlane(item);
+    first = __builtin_amdgcn_readfirstlane(f);
+    last = __builtin_amdgcn_readfirstlane(l);
 }
 
 template <bool COUNT>
 __global__ __launch_bounds__(1024) void k_step(PassParams pp, uint32_t parity) {
     extern __shared__ float4 lds_nodes[];
     PassDesc* desc = pp.desc;
+    if (desc->n_items == 0) return;  // drained: iterations enqueued past the end of the pass cost a launch only
     // iteration descriptor -> LDS, behind the node image (16-byte aligned: n_lds_nodes * 32 bytes)
     uint32_t* s_prefix = (uint32_t*)(lds_nodes + 2 * pp.scene.n_lds_nodes);  // [NSHARD+1]
     uint32_t* s_incount = s_prefix + (MPT_NSHARD + 1);                        // [NSHARD]
@@ -172,9 +186,13 @@ __global__ __launch_bounds__(1024) void k_step(PassParams pp, uint32_t parity) {
     uint32_t n_rays = 0, n_paths = 0;
     WorkCount wc = {0, 0, 0};
 
-    for (;;) {
-        const uint32_t item = fetch_item(desc, s_range_end, home);
-        if (item == MPT_NONE) break;
+    const uint32_t waves_per_group = (gridDim.x * (blockDim.x >> 6) + MPT_NGROUP - 1) / MPT_NGROUP;
+    uint32_t item = 0, item_last = 0;
+    for (;; ++item) {
+        if (item >= item_last) {
+            fetch_items(pp.ctr, s_range_end, home, waves_per_group, item, item_last);
+            if (item == MPT_NONE) break;
+        }
         PathState ps;
         PathRngDev g;
         bool valid;
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(1024) void k_step(PassParams pp, uint32_t parity) {
             const uint32_t n = (uint32_t)__popcll(mask);
             const uint32_t shard = item & (MPT_NSHARD - 1);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&desc->out_count[shard], n);
+            if (lane == 0) base = atomicAdd(&pp.ctr[MPT_CTR_OUT(shard)], n);
             base = __shfl(base, 0);
             if (alive) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -269,12 +287,12 @@ __global__ __launch_bounds__(1024) void k_step(PassParams pp, uint32_t parity) {
 }
 
 // one wave; lane 0 does the (tiny) serial work
-__device__ void advance_desc(PassDesc* d, volatile uint32_t* host_done) {
+__device__ void advance_desc(PassDesc* d, uint32_t* ctr, volatile uint32_t* host_done) {
     uint32_t items = 0;
     for (uint32_t s = 0; s < MPT_NSHARD; ++s) {
-        uint32_t c = d->out_count[s];
+        uint32_t c = ctr[MPT_CTR_OUT(s)];
         d->in_count[s] = c;
-        d->out_count[s] = 0;
+        ctr[MPT_CTR_OUT(s)] = 0;
         d->item_prefix[s] = items;
         items += (c + 63u) >> 6;
     }
@@ -289,7 +307,7 @@ __device__ void advance_desc(PassDesc* d, volatile uint32_t* host_done) {
     for (uint32_t g = 0; g < MPT_NGROUP; ++g) {
         uint32_t b = (uint32_t)(((unsigned long long)n * g) / MPT_NGROUP);
         uint32_t e = (uint32_t)(((unsigned long long)n * (g + 1)) / MPT_NGROUP);
-        d->cursor[g] = b;
+        ctr[MPT_CTR_CURSOR(g)] = b;
         d->range_end[g] = e;
     }
     d->done = (n == 0) ? 1u : 0u;
@@ -297,19 +315,20 @@ __device__ void advance_desc(PassDesc* d, volatile uint32_t* host_done) {
     if (host_done) *host_done = d->done | (d->overflow << 1);
 }
 
-__global__ void k_begin_pass(PassDesc* d, uint32_t total_paths, uint32_t slots_items, volatile uint32_t* host_done) {
+__global__ void k_begin_pass(PassDesc* d, uint32_t* ctr, uint32_t total_paths, uint32_t slots_items,
+                             volatile uint32_t* host_done) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (uint32_t s = 0; s < MPT_NSHARD; ++s) d->out_count[s] = 0;
+    for (uint32_t s = 0; s < MPT_NSHARD; ++s) ctr[MPT_CTR_OUT(s)] = 0;
     d->next_path = 0;
     d->total_paths = total_paths;
     d->slots_items = slots_items;
     d->overflow = 0;
-    advance_desc(d, host_done);
+    advance_desc(d, ctr, host_done);
 }
 
-__global__ void k_advance(PassDesc* d, volatile uint32_t* host_done) {
+__global__ void k_advance(PassDesc* d, uint32_t* ctr, volatile uint32_t* host_done) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    advance_desc(d, host_done);
+    advance_desc(d, ctr, host_done);
 }
 
 // Megakernel variant: one thread per path, whole bounce loop in registers (A/B baseline).
@@ -481,11 +500,13 @@ struct mpt_ctx {
     float4* d_slots = nullptr;
     uint64_t slots_cap = 0;
     PassDesc* d_desc = nullptr;
+    uint32_t* d_ctr = nullptr;
     uint32_t* h_done = nullptr;  // pinned, device-visible
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
     // launch geometry
     int wg_size = 1024;
+    bool time_kernels = true;
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
     size_t lds_budget = 60 * 1024;
     mpt_stats stats = {};
@@ -538,6 +559,8 @@ extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(MPT_ERR_HIP);
     if (hipMalloc(&ctx->d_desc, sizeof(PassDesc)) != hipSuccess) return bail(MPT_ERR_HIP);
     if (hipMemset(ctx->d_desc, 0, sizeof(PassDesc)) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipMalloc(&ctx->d_ctr, MPT_CTR_WORDS * 4) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipMemset(ctx->d_ctr, 0, MPT_CTR_WORDS * 4) != hipSuccess) return bail(MPT_ERR_HIP);
     if (hipHostMalloc((void**)&ctx->h_done, 64, hipHostMallocMapped) != hipSuccess) return bail(MPT_ERR_HIP);
     *ctx->h_done = 0;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) return bail(MPT_ERR_HIP);
@@ -545,6 +568,7 @@ extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_WG_SIZE"))) ctx->wg_size = atoi(e);
     if ((e = getenv("MPT_WGS_PER_CU"))) ctx->wgs_per_cu = atoi(e);
     if ((e = getenv("MPT_LDS_BYTES"))) ctx->lds_budget = (size_t)atol(e);
+    ctx->time_kernels = !((e = getenv("MPT_NO_KERNEL_EVENTS")) && atoi(e));
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 1024;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
@@ -581,6 +605,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_pixel_seed);
     hipFree(ctx->d_slots);
     hipFree(ctx->d_desc);
+    hipFree(ctx->d_ctr);
     free_queues(ctx);
     hipHostFree(ctx->h_done);
     hipEventDestroy(ctx->ev0);
@@ -990,6 +1015,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     pp.q[1] = ctx->q[1];
     pp.shard_cap = ctx->shard_cap;
     pp.desc = ctx->d_desc;
+    pp.ctr = ctx->d_ctr;
     pp.slots = ctx->d_slots;
     pp.pixel_seed = ctx->d_pixel_seed;
     const mpt_uniforms& u = ctx->u;
@@ -1032,7 +1058,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     const int grid = ctx->prop.multiProcessorCount * per_cu;
     hipStream_t st = ctx->stream;
     *ctx->h_done = 0;
-    hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, ctx->d_desc, (uint32_t)pass_paths, slots_items,
+    hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, ctx->d_desc, ctx->d_ctr, (uint32_t)pass_paths, slots_items,
                        (volatile uint32_t*)dev_done);
     if (p->pipeline == MPT_PIPE_MEGAKERNEL) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1073,11 +1099,15 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     uint32_t parity = 0;
     uint64_t launched = 0;
-    const uint64_t est = (pass_paths * 2) / ((uint64_t)slots_items * 64) + (uint64_t)p->max_depth + 2;
+    // Expected number of iterations: every slot of an iteration retires one ray; a pass traces about
+    // 1.7 rays per path here, and the queue drains over at most max_depth further iterations.  All of them
+    // are enqueued without a host round trip (an iteration that finds no work exits at once); the device
+    // publishes `done` to pinned host memory and the host only tops up if the estimate was short.
+    const uint64_t est = (pass_paths * 7 / 4) / ((uint64_t)slots_items * 64) + (uint64_t)p->max_depth + 2;
     const uint64_t hard_cap = est * 8 + 64;
-    const int batch = 4;
+    uint64_t batch = est;
     for (;;) {
-        for (int b = 0; b < batch; ++b) {
+        for (uint64_t b = 0; b < batch; ++b) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (time_kernels) {
                 e0 = get_event();
@@ -1093,7 +1123,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
                 HIPCHK(hipEventRecord(e1, st));
                 timed.emplace_back(e0, e1);
             }
-            hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->d_desc, (volatile uint32_t*)dev_done);
+            hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->d_desc, ctx->d_ctr, (volatile uint32_t*)dev_done);
             parity ^= 1u;
             launched++;
         }
@@ -1103,6 +1133,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
         if (flag & 2u) return fail(ctx, MPT_ERR_OVERFLOW, "ray queue overflow");
         if (flag & 1u) break;
         if (launched > hard_cap) return fail(ctx, MPT_ERR_HIP, "pass did not drain (internal)");
+        batch = 4;
     }
     if (time_kernels) {
         PassDesc hd;
@@ -1113,6 +1144,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, timed[i].first, timed[i].second));
             ctx->stats.trace_kernel_ms += ms;
+            if (getenv("MPT_DEBUG_ITERS")) fprintf(stderr, "[mpt] iter %zu: %.3f ms\n", i, ms);
         }
         ctx->stats.trace_launches += real;
     }
@@ -1151,7 +1183,7 @@ extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
         uint32_t S = std::min(s_max, p->sample_count - done);
         PassParams pp;
         uint32_t nlt = 0;
-        rc = run_pass(ctx, p, p->sample_begin + done, S, pp, nlt, true);
+        rc = run_pass(ctx, p, p->sample_begin + done, S, pp, nlt, ctx->time_kernels);
         if (rc) return rc;
         if (nlt) {
             uint32_t threads = nlt * 64u;

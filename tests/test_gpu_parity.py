@@ -1,0 +1,293 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bit-exact for integer work and for the philox images; per-pixel L2 < 1e-3 (north_star) where the
+device math library is involved (literal cos/sin).  Scene buffers come from the PRODUCT's host layer."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import CORNELL_CAM, host_scene, oracle_scene, pixel_l2, scene_path
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+L2_TOL = 1e-3
+
+
+def setup(ctx, name, W, H, cam=None, **uk):
+    from metalpathtracer_amd import host
+    sc, buf = host_scene(name)
+    ctx.upload_scene(*buf)
+    u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam, **uk)
+    ctx.resize(W, H)
+    ctx.set_uniforms(u)
+    uo = ob.Uniforms.from_buffer_copy(bytes(u))
+    return buf, uo
+
+
+def test_rng_known_answers_on_device(gpu_ctx):
+    seeds = np.array([0, 1, 2, 12345, 0xFFFFFFFF], np.uint32)
+    h, f = gpu_ctx.kat_pcg(seeds)
+    assert h.tolist() == [2891249901, 3639127469, 86804957, 261270601, 2144086741]
+    assert f[:3].tolist() == [np.float32(0.67317158), np.float32(0.84730041), np.float32(0.0202108547)]
+    rng = np.random.default_rng(0)
+    s = rng.integers(0, 2**32, 100000, dtype=np.uint64).astype(np.uint32)
+    h, f = gpu_ctx.kat_pcg(s)
+    L = ob.lib()
+    for i in range(0, s.size, 997):
+        assert h[i] == L.orc_pcg_hash(int(s[i])) and f[i] == np.float32(L.orc_pcg_float(int(s[i])))
+    ctr = rng.integers(0, 2**32, (4096, 4), dtype=np.uint64).astype(np.uint32)
+    key = rng.integers(0, 2**32, (4096, 2), dtype=np.uint64).astype(np.uint32)
+    ctr[0], key[0] = 0, 0
+    ctr[1], key[1] = 0xFFFFFFFF, 0xFFFFFFFF
+    ctr[2], key[2] = (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)
+    out = gpu_ctx.kat_philox(ctr, key)
+    assert out[0].tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]        # Random123 KATs
+    assert out[1].tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert out[2].tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    o = (C.c_uint32 * 4)()
+    for i in range(3, 4096, 61):
+        L.orc_philox((C.c_uint32 * 4)(*ctr[i].tolist()), (C.c_uint32 * 2)(*key[i].tolist()), o)
+        assert out[i].tolist() == list(o)
+    u = np.concatenate([np.linspace(0, 1, 200001, dtype=np.float32)[:-1],
+                        np.array([0.0, 0.125, 0.25, 0.375, 0.5, 0.875, 0.99999994], np.float32)])
+    sn, cs = gpu_ctx.kat_sincos(u)
+    a, b = C.c_float(), C.c_float()
+    for i in list(range(0, u.size, 211)) + list(range(u.size - 7, u.size)):
+        L.orc_sincos_2pi(float(u[i]), C.byref(a), C.byref(b))
+        assert sn[i] == np.float32(a.value) and cs[i] == np.float32(b.value)
+
+
+def test_closest_hit_matches_oracle_bitwise(gpu_ctx):
+    buf, _ = setup(gpu_ctx, "scene.xml", 64, 36)
+    rng = np.random.default_rng(1)
+    n = 4096
+    o = np.tile(np.array([0, 20, 50], np.float32), (n, 1)) + rng.normal(0, 2, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # edge cases: axis-parallel directions (1/0 = inf in the slab test), rays from inside the light sphere,
+    # rays grazing the big sphere, un-normalised and zero directions
+    extra_o = np.array([[0, 20, 50], [0, 20, 50], [0, 20, 50], [0, 20, 0], [0, 20, 0], [40, 100, 50], [-25, 5, 50],
+                        [0, 20, 50], [0, 20, 50]], np.float32)
+    extra_d = np.array([[0, 0, -1], [0, -1, 0], [1, 0, 0], [0, 0, 1], [0, 1, 0], [0, 0, -1], [0, 0, -1],
+                        [0, 0, -7.5], [0, 0, 0]], np.float32)
+    o = np.concatenate([o, extra_o])
+    d = np.concatenate([d, extra_d])
+    t, prim, nrm, front = gpu_ctx.trace_rays(o, d)
+    hits = 0
+    for i in range(o.shape[0]):
+        to, po, no, fo = ob.first_hit(o[i], d[i], buf)
+        assert po == prim[i], i
+        if po >= 0:
+            hits += 1
+            assert np.float32(to) == t[i] and fo == bool(front[i])
+            assert tuple(np.float32(x) for x in no) == tuple(nrm[i])
+        else:
+            assert np.isinf(t[i])
+    assert hits > 1000
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("name,W,H,cam,depth,spp,bsdf", [
+    ("scene.xml", 160, 90, None, 8, 8, 0),
+    ("scene.xml", 101, 67, None, 32, 4, 0),       # ragged size: partial 8x8 tiles on both edges
+    ("cornell.xml", 96, 96, CORNELL_CAM, 32, 8, 0),
+    ("glass.xml", 128, 72, None, 16, 8, 1),
+    ("bunny20.xml", 96, 54, None, 8, 2, 0),
+])
+def test_philox_image_bit_exact(gpu_ctx, name, W, H, cam, depth, spp, bsdf, pipeline):
+    from metalpathtracer_amd import capi
+    buf, uo = setup(gpu_ctx, name, W, H, cam=cam)
+    gpu_ctx.clear_sum()
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, seed=(11, 5),
+                   pipeline=pipeline, flags=capi.FLAG_COUNT_WORK)
+    got = gpu_ctx.read_sum()
+    ref, ct = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, accumulate=1,
+                        sample_count=spp, seed=(11, 5), threads=8)
+    assert pixel_l2(got / spp, ref / spp) < L2_TOL          # the north-star gate
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))   # what is actually achieved
+    st = gpu_ctx.stats()
+    assert (st["paths"], st["rays"], st["node_visits"], st["aabb_hits"], st["prim_tests"]) == (
+        ct["paths"], ct["rays"], ct["node_pops"], ct["aabb_pass"], ct["prim_tests"])
+
+
+def test_small_wavefront_width_and_sample_ranges(gpu_ctx):
+    """Tiny wavefront width (many iterations, queue shards nearly empty) and split sample ranges give the
+    same bits as one big call: the result must not depend on scheduling."""
+    from metalpathtracer_amd import capi
+    buf, uo = setup(gpu_ctx, "scene.xml", 120, 68)
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=6, seed=(3, 9))
+    whole = gpu_ctx.read_sum()
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_begin=0, sample_count=2, seed=(3, 9), slots_per_iter=512)
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_begin=2, sample_count=4, seed=(3, 9), slots_per_iter=4096)
+    parts = gpu_ctx.read_sum()
+    np.testing.assert_array_equal(whole.view(np.uint32), parts.view(np.uint32))
+    ref, _ = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, max_depth=8, accumulate=1, sample_count=6, seed=(3, 9), threads=8)
+    np.testing.assert_array_equal(whole.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_literal_frame_protocol(gpu_ctx, pipeline):
+    """The reference's actual per-frame behaviour (stuck RNG, running mean, frameCount off-by-one):
+    4 frames, host-seeded randomSeed, against the oracle's frame protocol."""
+    from metalpathtracer_amd import capi, host
+    W, H = 160, 90
+    sc, buf = host_scene("scene.xml")
+    gpu_ctx.upload_scene(*buf)
+    gpu_ctx.resize(W, H)
+    rs = host.host_seed_sequence(3)
+    last = np.zeros((H, W, 4), np.float32)
+    for f in range(1, 5):
+        u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), random_seed=rs, frame_count=f)
+        gpu_ctx.set_uniforms(u)
+        gpu_ctx.draw(rng_mode=capi.RNG_LITERAL, max_depth=32, pipeline=pipeline)
+        got = gpu_ctx.read_frame()
+        ref, _ = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG_LITERAL, max_depth=32,
+                           accumulate=0, last=last, threads=8)
+        assert pixel_l2(got, ref) < L2_TOL
+        assert np.abs(got - ref).max() < 1e-5
+        last = ref
+    assert got[H // 2, W // 2, 0] == pytest.approx(0.8, abs=1e-6)   # 4/5 at the light
+
+
+def test_renderer_facade_frames(gpu_ctx):
+    """host.Renderer = the reference's Renderer call order (constructor, drawableSizeWillChange, draw x N)."""
+    from metalpathtracer_amd import host
+    r = host.Renderer(0, scene_path("scene.xml"))
+    r.drawableSizeWillChange(128, 72)
+    sc, buf = oracle_scene("scene.xml")
+    last = np.zeros((72, 128, 4), np.float32)
+    for f in range(1, 4):
+        r.draw()
+        u = r.uniforms()
+        assert u.frameCount == f and list(u.randomSeed)[:3] == [0.0, 0.0, 0.0]   # SURVEY A.3-3 as shipped
+        got = r.readFrame()
+        ref, _ = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG_LITERAL, max_depth=32,
+                           accumulate=0, last=last, threads=8)
+        assert pixel_l2(got, ref) < L2_TOL
+        last = ref
+    assert got[36, 64, :3].tolist() == pytest.approx([0.75, 0.75, 0.75], abs=1e-6)  # k/(k+1) at the light
+    r.close()
+
+
+def test_tile_sharding_sums_to_single_gpu_image(gpu_ctx):
+    """N logical ranks rendered one after another into separate buffers, summed on the host,
+    equal the 1-rank image bit for bit (each pixel is owned by exactly one rank)."""
+    from metalpathtracer_amd import capi
+    buf, uo = setup(gpu_ctx, "scene.xml", 200, 120)
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=4)
+    one = gpu_ctx.read_sum()
+    for n in (2, 3, 8):
+        total = np.zeros_like(one)
+        owned = np.zeros(one.shape[:2], np.int32)
+        for r in range(n):
+            gpu_ctx.clear_sum()
+            gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=4, shard_rank=r, shard_count=n)
+            part = gpu_ctx.read_sum()
+            owned += (part[..., 3] > 0)
+            total += part
+        assert (owned == 1).all()
+        np.testing.assert_array_equal(total.view(np.uint32), one.view(np.uint32))
+
+
+def test_error_paths(gpu_ctx):
+    from metalpathtracer_amd import capi
+    ctx = capi.Context(0)
+    with pytest.raises(capi.MptError) as e:
+        ctx.render(sample_count=1)
+    assert e.value.status == 5  # MPT_ERR_NOT_READY
+    sc, (bvh, prims, mats, idx) = host_scene("scene.xml")
+    bad = bvh.copy()
+    bad[1, 0, 3] = np.int32(0).view(np.float32) if bad[1, 1, 3].view(np.int32) <= 0 else bad[1, 0, 3]
+    bad[0, 1, 3] = np.array(0, np.int32).view(np.float32)       # right child = 0 -> cycle
+    with pytest.raises(capi.MptError) as e:
+        ctx.upload_scene(bad, prims, mats, idx)
+    assert e.value.status == 4  # MPT_ERR_BAD_SCENE
+    bad = idx.copy()
+    bad[5] = 10**6
+    with pytest.raises(capi.MptError) as e:
+        ctx.upload_scene(bvh, prims, mats, bad)
+    assert e.value.status == 4
+    ctx.upload_scene(bvh, prims, mats, idx)
+    ctx.resize(32, 32)
+    from metalpathtracer_amd import host
+    ctx.set_uniforms(host.make_uniforms(64, 64, 1))
+    with pytest.raises(capi.MptError) as e:
+        ctx.render(sample_count=1)
+    assert e.value.status == 1  # uniforms.screenSize != resize
+    ctx.close()
+
+
+def test_material_guard_and_long_leaf(gpu_ctx):
+    """primitiveCount smaller than the real count trips the material-index guard (PathTracing.h:234-236);
+    a hand-made single-leaf BVH with 40 primitives exercises the >16 leaf split of the device layout."""
+    from metalpathtracer_amd import capi, host
+    rng = np.random.default_rng(4)
+    sc = host.Scene()
+    o = ob.OracleScene()
+    for i in range(40):
+        c = rng.uniform(-3, 3, 3)
+        c[2] = rng.uniform(-6, -2)
+        a, b = c + rng.uniform(-1, 1, 3), c + rng.uniform(-1, 1, 3)
+        sc.addTriangle(c, a, b, albedo=(0.5, 0.6, 0.7))
+        o.add_triangle(c, a, b, albedo=(0.5, 0.6, 0.7))
+    sc.buildBVH()
+    o.build_bvh()
+    bvh, prims, mats, idx = sc.buffers()
+    # collapse to ONE leaf holding all 40 primitives
+    one = bvh[:1].copy()
+    one[0, 0, 3] = np.array(0, np.int32).view(np.float32)
+    one[0, 1, 3] = np.array(40, np.int32).view(np.float32)
+    idx1 = np.arange(40, dtype=np.int32)
+    gpu_ctx.upload_scene(one, prims, mats, idx1)
+    W, H = 64, 64
+    cam = dict(pos=(0, 0, 3), fwd=(0, 0, -1), up=(0, 1, 0), vfov=60.0)
+    for pc in (40, 17):
+        u = host.make_uniforms(W, H, pc, pc, cam=cam)
+        gpu_ctx.resize(W, H)
+        gpu_ctx.set_uniforms(u)
+        gpu_ctx.clear_sum()
+        gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=4)
+        got = gpu_ctx.read_sum()
+        ref, _ = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), (one, prims, mats, idx1), rng_mode=ob.RNG_PHILOX,
+                           max_depth=8, accumulate=1, sample_count=4, threads=4)
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE.json full size (1920x1080): size-independent properties instead of an oracle render —
+    determinism, sample-range additivity, shard additivity, wavefront == megakernel, and a 64-row band
+    compared with the oracle."""
+    from metalpathtracer_amd import capi
+    W, H = 1920, 1080
+    buf, uo = setup(gpu_ctx, "scene.xml", W, H)
+    kw = dict(rng_mode=capi.RNG_PHILOX, max_depth=8, seed=(1, 0))
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(sample_count=4, **kw)
+    a = gpu_ctx.read_sum()
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(sample_count=4, **kw)
+    np.testing.assert_array_equal(a.view(np.uint32), gpu_ctx.read_sum().view(np.uint32))       # deterministic
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(sample_count=4, pipeline=capi.PIPE_MEGAKERNEL, **kw)
+    np.testing.assert_array_equal(a.view(np.uint32), gpu_ctx.read_sum().view(np.uint32))       # pipelines agree
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(sample_begin=0, sample_count=1, **kw)
+    gpu_ctx.render(sample_begin=1, sample_count=3, **kw)
+    np.testing.assert_array_equal(a.view(np.uint32), gpu_ctx.read_sum().view(np.uint32))       # additive in samples
+    total = np.zeros_like(a)
+    for r in range(2):
+        gpu_ctx.clear_sum()
+        gpu_ctx.render(sample_count=4, shard_rank=r, shard_count=2, **kw)
+        total += gpu_ctx.read_sum()
+    np.testing.assert_array_equal(a.view(np.uint32), total.view(np.uint32))                    # additive in shards
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[..., :3] <= 4).all()        # per-sample clamp
+    band = (504, 568)   # crosses the horizon, the light sphere and the bunny
+    ref = np.zeros((H, W, 4), np.float32)
+    ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, max_depth=8, accumulate=1, sample_count=4, seed=(1, 0), out=ref,
+              rows=band)
+    np.testing.assert_array_equal(a[band[0]:band[1]].view(np.uint32), ref[band[0]:band[1]].view(np.uint32))
