@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s on scene.xml at 1920x1080, depth 8, 256 spp (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the whole 1920x1080 frame at --spp-per-step samples per pixel
+(default 64; the default K = 4 steps is exactly the 256 spp of the headline config).  Scene load, BVH build and
+upload happen before the timed region (inputs resident in HBM); the timed region holds the K render steps and,
+for N > 1, the one RCCL reduce of the HDR framebuffer.  N > 1: one process per GPU, the 8x8 pixel tiles are
+interleaved over the ranks (strong scaling: the job is fixed, `value` = all rays of the job / max-over-ranks time).
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel vs the HBM roof, algorithmic bytes per ray per SURVEY.md 8(d)
+  cpu_baseline  the CPU oracle (this repo's restatement of the reference algorithm; the reference has no CPU
+                path) timed on the host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+B_QUEUE = 168.0        # compulsory wavefront-queue bytes per ray
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "scene.xml"))
+    ap.add_argument("--pipeline", default=os.environ.get("MPT_BENCH_PIPELINE", "default"),
+                    choices=["default", "wavefront", "megakernel"])
+    ap.add_argument("--slots", type=int, default=0, help="wavefront width (ray slots per iteration), 0 = default")
+    ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def host_cores():
+    """Threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    cap = int(os.environ.get("MPT_CPU_THREADS", "0"))
+    return min(n, cap) if cap > 0 else n
+
+
+def cpu_baseline(args, scene_buffers, prim_count, tri_count):
+    """Time the CPU oracle on all host cores on a bounded sample (same scene, size, depth, RNG; fewer spp).
+    Also returns the per-ray work counters that price the algorithmic bytes per ray (reference traversal)."""
+    from oracle import binding as ob
+    cores = host_cores()
+    u = ob.make_uniforms(args.width, args.height, prim_count, tri_count)
+    # sized for roughly 10-30 core-seconds: ~3.4 Mrays/s/core, 1.68 rays/path
+    spp = max(1, args.cpu_spp)
+    t0 = time.perf_counter()
+    _, ct = ob.render(u, scene_buffers, rng_mode=ob.RNG_PHILOX, max_depth=args.depth, accumulate=1, sample_count=spp,
+                      seed=(1, 0), threads=cores)
+    dt = time.perf_counter() - t0
+    n_node = ct["node_pops"] / ct["rays"]
+    n_prim = ct["prim_tests"] / ct["rays"]
+    h = ct["bounces"] / ct["rays"]
+    return dict(value=ct["rays"] / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
+                sample="%dx%d, %d spp, depth %d, philox seed (1,0): %d rays in %.2f s on %d threads"
+                       % (args.width, args.height, spp, args.depth, ct["rays"], dt, cores)), (n_node, n_prim, h)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    from metalpathtracer_amd import capi, distributed as D, host
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path is the product and there is no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        D.init_from_env(backend="nccl")
+        import torch.distributed as dist
+
+    # ---- untimed setup: ingest, BVH, upload (the product's own host layer) ----
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(args.scene, sc)
+    if st != 0:
+        sys.exit("cannot load %s: %s" % (args.scene, log))
+    sc.buildBVH()
+    buffers = sc.buffers()
+    P, T = sc.getPrimitiveCount(), sc.getTriangleCount()
+    ctx = capi.Context(local)
+    ctx.upload_scene(*buffers)
+    W, H = args.width, args.height
+    ctx.resize(W, H)
+    ctx.set_uniforms(host.make_uniforms(W, H, P, T))
+    fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    ctx.set_sum_buffer(fb.data_ptr())
+    pipe = {"default": capi.DEFAULT_PIPELINE, "wavefront": capi.PIPE_WAVEFRONT, "megakernel": capi.PIPE_MEGAKERNEL}[
+        args.pipeline]
+    kw = dict(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_LAMBERT, max_depth=args.depth, pipeline=pipe, seed=(1, 0),
+              shard_rank=rank, shard_count=world, slots_per_iter=args.slots)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    spp = args.spp_per_step
+    for w in range(args.warmup):
+        ctx.render(sample_begin=w * spp, sample_count=spp, **kw)
+    if world > 1:  # warm the collective too
+        D.reduce_framebuffer(fb.clone())
+    fb.zero_()
+    ctx.reset_stats()
+    kernel_ms = 0.0
+    launches = 0
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ctx.render(sample_begin=k * spp, sample_count=spp, **kw)
+        s = ctx.stats()
+        kernel_ms += s["trace_kernel_ms"]      # HIP events on the context's own stream, around the dominant kernel
+        launches += s["trace_launches"]
+    if world > 1:
+        D.reduce_framebuffer(fb)               # ONE reduce(sum) of the HDR framebuffer to rank 0 (RCCL)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    rays_local = st["rays"]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays_local, st["paths"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_total, paths_total = int(r[0].item()), int(r[1].item())
+    else:
+        rays_total, paths_total = rays_local, st["paths"]
+
+    if rank == 0:
+        mean = (fb[..., :3].double().mean(dim=(0, 1)) / (args.steps * spp)).tolist()
+        out = {
+            "metric": "Mrays/s at 1920x1080x256spp on scene.xml",
+            "value": rays_total / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "assets/scene.xml (the reference's bundled scene, mesh path remapped) — no dataset involved",
+            "config": {
+                "workload": "scene.xml %dx%d, %d spp (%d steps x %d), depth %d" % (W, H, args.steps * spp, args.steps,
+                                                                                  spp, args.depth),
+                "prims": P, "bvh_nodes": sc.getBVHNodeCount(), "rng": "philox4x32-10 (pixel,sample,bounce)",
+                "pipeline": {capi.PIPE_WAVEFRONT: "wavefront", capi.PIPE_MEGAKERNEL: "megakernel"}.get(pipe, str(pipe)),
+                "parallelism": "8x8-tile interleave over %d rank(s)%s" % (world, " + 1 RCCL reduce(sum) of the HDR framebuffer" if world > 1 else ""),
+                "paths": paths_total, "rays": rays_total, "rays_per_path": rays_total / max(1, paths_total),
+                "image_mean_rgb": mean,
+            },
+        }
+        n_node, n_prim, h = 7.52, 3.59, 0.405   # SURVEY.md App. C.5 (used only if the CPU leg is skipped)
+        if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
+            out["cpu_baseline"], (n_node, n_prim, h) = cpu_baseline(args, buffers, P, T)
+        b_ray = B_QUEUE + 32.0 * n_node + 52.0 * n_prim + 32.0 * h
+        if launches and kernel_ms > 0:
+            rays_per_launch = rays_local / launches
+            sec_per_launch = kernel_ms * 1e-3 / launches
+            achieved = b_ray * rays_per_launch / sec_per_launch / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_step" if pipe == capi.PIPE_WAVEFRONT else "k_megakernel",
+                "launches": launches, "avg_launch_ms": kernel_ms / launches,
+                "bytes_per_ray": b_ray, "n_node": n_node, "n_prim": n_prim, "h": h,
+                "rays_per_launch": rays_per_launch,
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

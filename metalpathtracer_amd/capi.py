@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libmpt_hip.so")
 RNG_LITERAL, RNG_PHILOX = 0, 1
 BSDF_LAMBERT, BSDF_SCATTER = 0, 1
 PIPE_WAVEFRONT, PIPE_MEGAKERNEL = 0, 1
+DEFAULT_PIPELINE = PIPE_MEGAKERNEL  # fastest measured pipeline on MI355X (DESIGN.md "Pipelines, measured")
 FLAG_COUNT_WORK = 1
 
 STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT_ERR_HIP",
