@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 B_QUEUE = 168.0        # compulsory wavefront-queue bytes per ray
+PIPE_NAMES = {0: "wavefront (global SoA queues)", 1: "megakernel", 2: "wave-local wavefront"}
 
 
 def parse():
@@ -40,7 +41,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "scene.xml"))
     ap.add_argument("--pipeline", default=os.environ.get("MPT_BENCH_PIPELINE", "default"),
-                    choices=["default", "wavefront", "megakernel"])
+                    choices=["default", "wavefront", "megakernel", "wavelocal"])
     ap.add_argument("--slots", type=int, default=0, help="wavefront width (ray slots per iteration), 0 = default")
     ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,8 +118,8 @@ def main():
     ctx.set_uniforms(host.make_uniforms(W, H, P, T))
     fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     ctx.set_sum_buffer(fb.data_ptr())
-    pipe = {"default": capi.DEFAULT_PIPELINE, "wavefront": capi.PIPE_WAVEFRONT, "megakernel": capi.PIPE_MEGAKERNEL}[
-        args.pipeline]
+    pipe = {"default": capi.DEFAULT_PIPELINE, "wavefront": capi.PIPE_WAVEFRONT, "megakernel": capi.PIPE_MEGAKERNEL,
+            "wavelocal": capi.PIPE_WAVELOCAL}[args.pipeline]
     kw = dict(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_LAMBERT, max_depth=args.depth, pipeline=pipe, seed=(1, 0),
               shard_rank=rank, shard_count=world, slots_per_iter=args.slots)
 
@@ -179,7 +180,7 @@ def main():
                 "workload": "scene.xml %dx%d, %d spp (%d steps x %d), depth %d" % (W, H, args.steps * spp, args.steps,
                                                                                   spp, args.depth),
                 "prims": P, "bvh_nodes": sc.getBVHNodeCount(), "rng": "philox4x32-10 (pixel,sample,bounce)",
-                "pipeline": {capi.PIPE_WAVEFRONT: "wavefront", capi.PIPE_MEGAKERNEL: "megakernel"}.get(pipe, str(pipe)),
+                "pipeline": PIPE_NAMES[pipe],
                 "parallelism": "8x8-tile interleave over %d rank(s)%s" % (world, " + 1 RCCL reduce(sum) of the HDR framebuffer" if world > 1 else ""),
                 "paths": paths_total, "rays": rays_total, "rays_per_path": rays_total / max(1, paths_total),
                 "image_mean_rgb": mean,
@@ -196,7 +197,7 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_step" if pipe == capi.PIPE_WAVEFRONT else "k_megakernel",
+                "kernel": {0: "k_step", 1: "k_megakernel", 2: "k_wavelocal"}[pipe],
                 "launches": launches, "avg_launch_ms": kernel_ms / launches,
                 "bytes_per_ray": b_ray, "n_node": n_node, "n_prim": n_prim, "h": h,
                 "rays_per_launch": rays_per_launch,

@@ -56,8 +56,9 @@ enum { MPT_RNG_LITERAL = 0,  /* bit-faithful to the reference's stuck PCG stream
        MPT_RNG_PHILOX = 1 }; /* Philox4x32-10, counter (pixel, sample, bounce, 0): the benchmark RNG  */
 enum { MPT_BSDF_LAMBERT = 0, /* what rayColor executes (PathTracing.h:251-255)                        */
        MPT_BSDF_SCATTER = 1 }; /* + mirror / dielectric per Scatter.h:22-43 (dead code in the ref)    */
-enum { MPT_PIPE_WAVEFRONT = 0,  /* SoA ray queues + wave64 ballot compaction (default)                */
-       MPT_PIPE_MEGAKERNEL = 1 }; /* one thread per path, whole bounce loop in registers              */
+enum { MPT_PIPE_WAVEFRONT = 0,  /* global SoA ray queues + wave64 ballot compaction, one kernel/bounce */
+       MPT_PIPE_MEGAKERNEL = 1, /* one thread per path, whole bounce loop in registers                */
+       MPT_PIPE_WAVELOCAL = 2 };/* persistent waves, wave-private ray rings + ballot compaction        */
 
 typedef struct mpt_render_params {
     int32_t rng_mode;        /* MPT_RNG_*                                                             */

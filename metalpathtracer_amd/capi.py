@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(_PKG, "lib", "libmpt_hip.so")
 
 RNG_LITERAL, RNG_PHILOX = 0, 1
 BSDF_LAMBERT, BSDF_SCATTER = 0, 1
-PIPE_WAVEFRONT, PIPE_MEGAKERNEL = 0, 1
-DEFAULT_PIPELINE = PIPE_MEGAKERNEL  # fastest measured pipeline on MI355X (DESIGN.md "Pipelines, measured")
+PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL = 0, 1, 2
+DEFAULT_PIPELINE = PIPE_WAVELOCAL  # fastest measured pipeline on MI355X (DESIGN.md "Pipelines, measured")
 FLAG_COUNT_WORK = 1
 
 STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT_ERR_HIP",
@@ -176,7 +176,7 @@ class Context:
         self.width, self.height = int(w), int(h)
 
     @staticmethod
-    def params(rng_mode=RNG_PHILOX, bsdf_mode=BSDF_LAMBERT, max_depth=32, pipeline=PIPE_WAVEFRONT, sample_begin=0,
+    def params(rng_mode=RNG_PHILOX, bsdf_mode=BSDF_LAMBERT, max_depth=32, pipeline=DEFAULT_PIPELINE, sample_begin=0,
                sample_count=1, seed=(1, 0), shard_rank=0, shard_count=1, slots_per_iter=0, flags=0):
         return RenderParams(rng_mode, bsdf_mode, max_depth, pipeline, sample_begin, sample_count, seed[0], seed[1],
                             shard_rank, shard_count, slots_per_iter, flags)

@@ -18,7 +18,7 @@ static void usage() {
     std::puts(
         "mpt_render --scene scene.xml [--asset-root DIR] [--width 1280] [--height 720]\n"
         "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter]\n"
-        "           [--pipeline wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
+        "           [--pipeline wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
         "  --frames N   run the reference's frame protocol (N draw() calls, running mean) instead of batch spp");
 }
 
@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     std::memset(&prm, 0, sizeof prm);
     prm.rng_mode = MPT_RNG_PHILOX;
     prm.shard_count = 1;
+    prm.pipeline = MPT_PIPE_WAVELOCAL;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* {
@@ -51,7 +52,11 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next();
         else if (a == "--rng") prm.rng_mode = std::strcmp(next(), "literal") == 0 ? MPT_RNG_LITERAL : MPT_RNG_PHILOX;
         else if (a == "--bsdf") prm.bsdf_mode = std::strcmp(next(), "scatter") == 0 ? MPT_BSDF_SCATTER : MPT_BSDF_LAMBERT;
-        else if (a == "--pipeline") prm.pipeline = std::strcmp(next(), "megakernel") == 0 ? MPT_PIPE_MEGAKERNEL : MPT_PIPE_WAVEFRONT;
+        else if (a == "--pipeline") {
+            const char* v = next();
+            prm.pipeline = std::strcmp(v, "megakernel") == 0 ? MPT_PIPE_MEGAKERNEL
+                           : std::strcmp(v, "wavefront") == 0 ? MPT_PIPE_WAVEFRONT : MPT_PIPE_WAVELOCAL;
+        }
         else {
             usage();
             return a == "--help" ? 0 : 2;

@@ -118,97 +118,121 @@ struct WorkCount {
     uint32_t node_visits, aabb_hits, prim_tests;
 };
 
+// Primitives of one leaf, in index order — PathTracing.h:106-186.
+template <bool COUNT>
+__device__ __forceinline__ void leaf_test(const SceneDev& sc, uint32_t first, uint32_t count, F3 o, F3 d,
+                                          float& best_t, int& best_prim, WorkCount& wc) {
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 p0 = sc.prims[3 * (first + k)];
+        const float4 p1 = sc.prims[3 * (first + k) + 1];
+        if (COUNT) wc.prim_tests++;
+        const int ptype = (int)p0.w;
+        if (ptype == 1) {  // PathTracing.h:143-176 Moeller-Trumbore, two-sided
+            const float4 p2 = sc.prims[3 * (first + k) + 2];
+            F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
+            F3 h = cross3(d, e2);
+            float a = dot3(e1, h);
+            if (fabsf(a) > 1e-5f) {
+                float f = 1.0f / a;
+                F3 s = o - v0;
+                float u = f * dot3(s, h);
+                if (u >= 0.0f && u <= 1.0f) {
+                    F3 q = cross3(s, e1);
+                    float v = f * dot3(d, q);
+                    if (v >= 0.0f && u + v <= 1.0f) {
+                        float tt = f * dot3(e2, q);
+                        if (tt > 0.0001f && tt < best_t) {
+                            best_t = tt;
+                            best_prim = (int)(first + k);
+                        }
+                    }
+                }
+            }
+        } else if (ptype == 0) {  // PathTracing.h:120-142 sphere, near root only
+            F3 c = f3(p0.x, p0.y, p0.z);
+            float radius = p1.x;
+            F3 oc = o - c;
+            float a = dot3(d, d);
+            float b = dot3(oc, d);
+            float cc = dot3(oc, oc) - radius * radius;
+            float disc = b * b - a * cc;
+            if (disc > 0.0f) {
+                float sq = sqrtf(disc);
+                float temp = (-b - sq) / a;
+                if (temp < best_t && temp > 0.0001f) {
+                    best_t = temp;
+                    best_prim = (int)(first + k);
+                }
+            }
+        }
+    }
+}
+
 // Closest hit — PathTracing.h:75-204.  Visits nodes and tests primitives in exactly the reference's
 // order (right child first, leaf primitives in index order), so ties resolve identically.
-template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const SceneDev& sc, const float4* __restrict__ lds_nodes, F3 o, F3 d,
+// LDS node image: an explicit address-space-3 pointer so that node fetches are ds_read_b128, never flat loads
+// (a generic pointer selected between LDS and global turns into flat_load: measured 0 LDS reads per ray).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) v4f* LdsNodes;
+
+template <bool COUNT, bool ALL_LDS>
+__device__ __forceinline__ void closest_hit(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d,
                                             float& best_t, int& best_prim, WorkCount& wc) {
     const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;  // PathTracing.h:61 (per call there)
     best_t = INFINITY;
     best_prim = -1;
     uint32_t i = 0;
     const uint32_t n_nodes = sc.n_nodes, n_lds = sc.n_lds_nodes;
-    while (i < n_nodes) {
-        float4 n0, n1;
-        if (i < n_lds) {
-            n0 = lds_nodes[2 * i];
-            n1 = lds_nodes[2 * i + 1];
-        } else {
-            n0 = sc.nodes[2 * i];
-            n1 = sc.nodes[2 * i + 1];
-        }
-        // PathTracing.h:52-72 slab test with tMin = 1e-4, tMax = best t.  The per-axis early-outs
-        // are equivalent to one test after the third axis (tMin only grows, tMax only shrinks).
-        float t0 = (n0.x - o.x) * idx, t1 = (n1.x - o.x) * idx;
-        float lo = fmaxf(0.0001f, idx < 0.0f ? t1 : t0);
-        float hi = fminf(best_t, idx < 0.0f ? t0 : t1);
-        t0 = (n0.y - o.y) * idy;
-        t1 = (n1.y - o.y) * idy;
-        lo = fmaxf(lo, idy < 0.0f ? t1 : t0);
-        hi = fminf(hi, idy < 0.0f ? t0 : t1);
-        t0 = (n0.z - o.z) * idz;
-        t1 = (n1.z - o.z) * idz;
-        lo = fmaxf(lo, idz < 0.0f ? t1 : t0);
-        hi = fminf(hi, idz < 0.0f ? t0 : t1);
-        const bool box = hi > lo;
-        const int A = __float_as_int(n0.w), B = __float_as_int(n1.w);
-        if (COUNT) {
-            wc.node_visits++;
-            wc.aabb_hits += box ? 1u : 0u;
-        }
-        if (B >= 0) {
-            i = box ? (uint32_t)A : (uint32_t)B;
-            continue;
-        }
-        if (box) {
-            const uint32_t enc = (uint32_t)(-(B + 1));
-            const uint32_t first = enc >> 4, count = (enc & 15u) + 1u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4 p0 = sc.prims[3 * (first + k)];
-                const float4 p1 = sc.prims[3 * (first + k) + 1];
-                if (COUNT) wc.prim_tests++;
-                const int ptype = (int)p0.w;
-                if (ptype == 1) {  // PathTracing.h:143-176 Moeller-Trumbore, two-sided
-                    const float4 p2 = sc.prims[3 * (first + k) + 2];
-                    F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
-                    F3 h = cross3(d, e2);
-                    float a = dot3(e1, h);
-                    if (fabsf(a) > 1e-5f) {
-                        float f = 1.0f / a;
-                        F3 s = o - v0;
-                        float u = f * dot3(s, h);
-                        if (u >= 0.0f && u <= 1.0f) {
-                            F3 q = cross3(s, e1);
-                            float v = f * dot3(d, q);
-                            if (v >= 0.0f && u + v <= 1.0f) {
-                                float tt = f * dot3(e2, q);
-                                if (tt > 0.0001f && tt < best_t) {
-                                    best_t = tt;
-                                    best_prim = (int)(first + k);
-                                }
-                            }
-                        }
-                    }
-                } else if (ptype == 0) {  // PathTracing.h:120-142 sphere, near root only
-                    F3 c = f3(p0.x, p0.y, p0.z);
-                    float radius = p1.x;
-                    F3 oc = o - c;
-                    float a = dot3(d, d);
-                    float b = dot3(oc, d);
-                    float cc = dot3(oc, oc) - radius * radius;
-                    float disc = b * b - a * cc;
-                    if (disc > 0.0f) {
-                        float sq = sqrtf(disc);
-                        float temp = (-b - sq) / a;
-                        if (temp < best_t && temp > 0.0001f) {
-                            best_t = temp;
-                            best_prim = (int)(first + k);
-                        }
-                    }
+    // "while-while" form: every lane first walks box tests until IT has a leaf to test (or is done); only then
+    // does the wave run the primitive loop, for all lanes with a pending leaf at once.  A lane performs exactly
+    // the same sequence of box and primitive tests as the straightforward loop (same order, same best_t at each
+    // test), so the result is unchanged; what changes is that the long primitive loop is no longer executed for
+    // one or two lanes every time any lane reaches a leaf.
+    for (;;) {
+        uint32_t leaf_first = 0, leaf_count = 0;
+        while (i < n_nodes) {
+            float4 n0, n1;
+            if (ALL_LDS || i < n_lds) {
+                const v4f a = lds_nodes[2 * i], b = lds_nodes[2 * i + 1];
+                n0 = make_float4(a.x, a.y, a.z, a.w);
+                n1 = make_float4(b.x, b.y, b.z, b.w);
+            } else {
+                n0 = sc.nodes[2 * i];
+                n1 = sc.nodes[2 * i + 1];
+            }
+            // PathTracing.h:52-72 slab test with tMin = 1e-4, tMax = best t.  The per-axis early-outs
+            // are equivalent to one test after the third axis (tMin only grows, tMax only shrinks).
+            float t0 = (n0.x - o.x) * idx, t1 = (n1.x - o.x) * idx;
+            float lo = fmaxf(0.0001f, idx < 0.0f ? t1 : t0);
+            float hi = fminf(best_t, idx < 0.0f ? t0 : t1);
+            t0 = (n0.y - o.y) * idy;
+            t1 = (n1.y - o.y) * idy;
+            lo = fmaxf(lo, idy < 0.0f ? t1 : t0);
+            hi = fminf(hi, idy < 0.0f ? t0 : t1);
+            t0 = (n0.z - o.z) * idz;
+            t1 = (n1.z - o.z) * idz;
+            lo = fmaxf(lo, idz < 0.0f ? t1 : t0);
+            hi = fminf(hi, idz < 0.0f ? t0 : t1);
+            const bool box = hi > lo;
+            const int A = __float_as_int(n0.w), B = __float_as_int(n1.w);
+            if (COUNT) {
+                wc.node_visits++;
+                wc.aabb_hits += box ? 1u : 0u;
+            }
+            if (B >= 0) {
+                i = box ? (uint32_t)A : (uint32_t)B;
+            } else {
+                i = (uint32_t)A;
+                if (box) {
+                    const uint32_t enc = (uint32_t)(-(B + 1));
+                    leaf_first = enc >> 4;
+                    leaf_count = (enc & 15u) + 1u;
+                    break;
                 }
             }
         }
-        i = (uint32_t)A;
+        if (leaf_count == 0u) break;
+        leaf_test<COUNT>(sc, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
     }
 }
 

@@ -29,6 +29,13 @@
 #include "mpt.h"
 #include "mpt_device.h"
 
+// Minimum waves per SIMD the trace kernels are compiled for (2nd __launch_bounds__ argument).  The kernels are
+// latency-bound (dependent LDS / L2 reads per BVH step): 8 waves/SIMD (<= 64 VGPRs, 2 x 1024-thread workgroups
+// per CU next to 2 x 57 KB of LDS) measured faster than 4-5 waves/SIMD at 81-83 VGPRs.
+#ifndef MPT_MIN_WAVES
+#define MPT_MIN_WAVES 8
+#endif
+
 // =====================================================================================================
 // device-side structures
 // =====================================================================================================
@@ -163,8 +170,8 @@ __device__ __forceinline__ void fetch_items(uint32_t* ctr, const uint32_t* s_ran
     last = __builtin_amdgcn_readfirstlane(l);
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(1024) void k_step(PassParams pp, uint32_t parity) {
+template <bool COUNT, bool ALL_LDS>
+__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uint32_t parity) {
     extern __shared__ float4 lds_nodes[];
     PassDesc* desc = pp.desc;
     if (desc->n_items == 0) return;  // drained: iterations enqueued past the end of the pass cost a launch only
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_step(PassParams pp, uint32_t parity) {
         if (valid) {
             float t;
             int prim;
-            closest_hit<COUNT>(pp.scene, lds_nodes, ps.o, ps.d, t, prim, wc);
+            closest_hit<COUNT, ALL_LDS>(pp.scene, (LdsNodes)lds_nodes, ps.o, ps.d, t, prim, wc);
             n_rays++;
             alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
             if (!alive)  // PathTracing.h:258 per-sample clamp
@@ -332,8 +339,8 @@ __global__ void k_advance(PassDesc* d, uint32_t* ctr, volatile uint32_t* host_do
 }
 
 // Megakernel variant: one thread per path, whole bounce loop in registers (A/B baseline).
-template <bool COUNT>
-__global__ __launch_bounds__(1024) void k_megakernel(PassParams pp) {
+template <bool COUNT, bool ALL_LDS>
+__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams pp) {
     extern __shared__ float4 lds_nodes[];
     stage_nodes(pp.scene, lds_nodes);
     const uint32_t lane = threadIdx.x & 63u;
@@ -354,11 +361,150 @@ __global__ __launch_bounds__(1024) void k_megakernel(PassParams pp) {
         while (alive) {
             float t;
             int prim;
-            closest_hit<COUNT>(pp.scene, lds_nodes, ps.o, ps.d, t, prim, wc);
+            closest_hit<COUNT, ALL_LDS>(pp.scene, (LdsNodes)lds_nodes, ps.o, ps.d, t, prim, wc);
             n_rays++;
             alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
         }
         pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+    }
+    unsigned long long r = n_rays, p = n_paths, a = wc.node_visits, b = wc.aabb_hits, c = wc.prim_tests;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        p += __shfl_down(p, off);
+        if (COUNT) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+            c += __shfl_down(c, off);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&pp.desc->rays, r);
+        atomicAdd(&pp.desc->paths, p);
+        if (COUNT) {
+            atomicAdd(&pp.desc->node_visits, a);
+            atomicAdd(&pp.desc->aabb_hits, b);
+            atomicAdd(&pp.desc->prim_tests, c);
+        }
+    }
+}
+
+// Wave-local wavefront (MPT_PIPE_WAVELOCAL): the wavefront idea at wave scope.
+// Every persistent wave owns a private ring of 128 ray records (SoA, 16-byte fields, in global memory but
+// touched by this wave only, so it lives in L2) and alternates between two kinds of full-width steps:
+//   * ring holds >= 64 bounce rays  -> pop 64 of them, closest hit, one bounce of shading
+//   * otherwise                     -> take the next 8x8-pixel tile sample (64 new paths), generate the primary
+//                                      rays in registers, closest hit, one bounce of shading
+// Survivors of either step are compacted with a wave64 ballot + mbcnt prefix and appended to the ring.  Compared
+// with the global wavefront there is no kernel boundary, no shared counter and no atomic per step (the ring's
+// head and count are wave-uniform registers); compared with the megakernel every step runs with (nearly) all 64
+// lanes on rays of the same generation, instead of a tail of few long paths.  Path ids are handed out 1024 at a
+// time from the pass cursor (one atomic per 16 tile samples).
+#define MPT_WL_RING 128u
+#define MPT_WL_BLOCK 4096u  // upper bound of a claim
+template <bool COUNT, bool ALL_LDS>
+__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp, QueueDev ring, uint2* ring_px,
+                                                                 uint32_t wl_block) {
+    extern __shared__ float4 lds_nodes_raw[];
+    stage_nodes(pp.scene, lds_nodes_raw);
+    const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_paths = pp.desc->total_paths;
+    uint32_t* cursor = &pp.ctr[MPT_CTR_CURSOR(0)];
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t rbase = wave_id * MPT_WL_RING;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t head = 0, count = 0;  // wave-uniform ring state
+    uint32_t cur = 0, end = 0;     // wave-uniform private range of path ids (multiples of 64)
+    uint32_t seen = 0;             // cursor value at this wave's previous claim
+    bool exhausted = false;
+    uint32_t n_rays = 0, n_paths = 0;
+    WorkCount wc = {0, 0, 0};
+    for (;;) {
+        PathState ps;
+        PathRngDev g;
+        bool valid = false;
+        bool from_ring = count >= 64u;
+        if (!from_ring && !exhausted && cur == end) {
+            // guided self-scheduling on the pass cursor: claim remaining / (8 * waves) path ids, rounded to whole
+            // 64-path tile samples and clamped to [64, wl_block]: few atomics while there is plenty of work, fine
+            // grain at the end of the pass (tile samples differ ~5x in cost between sky and geometry)
+            uint32_t k = 0, blk = 0;
+            if (lane == 0) {
+                // `seen` = the cursor value this wave saw at its previous claim (no extra load of the hot line)
+                const uint32_t left = seen < total_paths ? total_paths - seen : 0u;
+                blk = (left / (8u * n_waves)) & ~63u;
+                blk = blk < 64u ? 64u : (blk > wl_block ? wl_block : blk);
+                k = atomicAdd(cursor, blk);
+            }
+            k = __builtin_amdgcn_readfirstlane(k);
+            blk = __builtin_amdgcn_readfirstlane(blk);
+            seen = k;
+            if (k >= total_paths) {
+                exhausted = true;
+            } else {
+                cur = k;
+                end = (k + blk < total_paths) ? k + blk : total_paths;
+            }
+        }
+        if (!from_ring && exhausted) {
+            if (count == 0u) break;
+            from_ring = true;  // drain what is left with a partial wave
+        }
+        if (from_ring) {
+            const uint32_t n = count < 64u ? count : 64u;
+            if (lane < n) {
+                const uint32_t at = rbase + ((head + lane) & (MPT_WL_RING - 1u));
+                const float4 a = ring.od[at], b = ring.dt[at], c = ring.tl[at];
+                const uint2 ia = ring.ia[at], pxs = ring_px[at];
+                ps.o = f3(a.x, a.y, a.z);
+                ps.d = f3(a.w, b.x, b.y);
+                ps.thr = f3(b.z, b.w, c.x);
+                ps.L = f3(c.y, c.z, c.w);
+                ps.La = __uint_as_float(ia.y);
+                ps.path = ia.x & 0x07FFFFFFu;
+                ps.bounce = ia.x >> 27;
+                g.pixel = pxs.x;
+                g.sample = pxs.y;
+                g.lit_seed = 0;
+                if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+                valid = true;
+            }
+            head = (head + n) & (MPT_WL_RING - 1u);
+            count -= n;
+        } else {
+            ps.path = cur + lane;
+            cur += 64u;
+            uint32_t px, py, sidx;
+            if (path_to_pixel(pp, ps.path, px, py, sidx)) {
+                gen_primary(pp, px, py, pp.sample_begin + sidx, ps, g);
+                valid = true;
+                n_paths++;
+            }
+        }
+        bool alive = false;
+        if (valid) {
+            float t;
+            int prim;
+            closest_hit<COUNT, ALL_LDS>(pp.scene, lds_nodes, ps.o, ps.d, t, prim, wc);
+            n_rays++;
+            alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
+            if (!alive)
+                pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+        }
+        const unsigned long long mask = __ballot(alive);
+        if (mask != 0ull) {
+            if (alive) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const uint32_t at = rbase + ((head + count + rank) & (MPT_WL_RING - 1u));
+                ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+                ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+                ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+                ring.ia[at] = make_uint2(ps.path | (ps.bounce << 27), __float_as_uint(ps.La));
+                ring_px[at] = make_uint2(g.pixel, g.sample);
+            }
+            count += (uint32_t)__popcll(mask);
+        }
     }
     unsigned long long r = n_rays, p = n_paths, a = wc.node_visits, b = wc.aabb_hits, c = wc.prim_tests;
     for (int off = 32; off > 0; off >>= 1) {
@@ -431,7 +577,7 @@ __global__ __launch_bounds__(1024) void k_trace_rays(SceneDev sc, const float* o
     float t;
     int prim;
     WorkCount wc = {0, 0, 0};
-    closest_hit<false>(sc, lds_nodes, ro, rd, t, prim, wc);
+    closest_hit<false, false>(sc, (LdsNodes)lds_nodes, ro, rd, t, prim, wc);
     t_out[i] = t;
     if (prim >= 0) {
         HitInfo h = finish_hit(sc, ro, rd, t, prim);
@@ -507,10 +653,29 @@ struct mpt_ctx {
     // launch geometry
     int wg_size = 1024;
     bool time_kernels = true;
+    QueueDev ring = {};        // wave-local wavefront: private rings, MPT_WL_RING records per wave
+    uint2* ring_px = nullptr;
+    size_t ring_waves = 0;
+    uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
     size_t lds_budget = 60 * 1024;
     mpt_stats stats = {};
 };
+
+// kernel variants: COUNT (work counters) x ALL_LDS (the whole BVH fits the LDS budget)
+static const void* step_kernel(bool count, bool all_lds) {
+    if (count) return all_lds ? (const void*)k_step<true, true> : (const void*)k_step<true, false>;
+    return all_lds ? (const void*)k_step<false, true> : (const void*)k_step<false, false>;
+}
+static const void* mega_kernel(bool count, bool all_lds) {
+    if (count) return all_lds ? (const void*)k_megakernel<true, true> : (const void*)k_megakernel<true, false>;
+    return all_lds ? (const void*)k_megakernel<false, true> : (const void*)k_megakernel<false, false>;
+}
+
+static const void* wavelocal_kernel(bool count, bool all_lds) {
+    if (count) return all_lds ? (const void*)k_wavelocal<true, true> : (const void*)k_wavelocal<true, false>;
+    return all_lds ? (const void*)k_wavelocal<false, true> : (const void*)k_wavelocal<false, false>;
+}
 
 #define MPT_LDS_EXTRA 256  // iteration descriptor copy behind the node image
 
@@ -569,13 +734,16 @@ extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_WGS_PER_CU"))) ctx->wgs_per_cu = atoi(e);
     if ((e = getenv("MPT_LDS_BYTES"))) ctx->lds_budget = (size_t)atol(e);
     ctx->time_kernels = !((e = getenv("MPT_NO_KERNEL_EVENTS")) && atoi(e));
+    if ((e = getenv("MPT_WL_BLOCK")) && atoi(e) >= 64) ctx->wl_block = (uint32_t)atoi(e) & ~63u;
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 1024;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
-    hipFuncSetAttribute((const void*)k_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_megakernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_megakernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < 2; ++a) {
+            hipFuncSetAttribute(step_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(mega_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(wavelocal_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
     hipFuncSetAttribute((const void*)k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return MPT_OK;
@@ -606,6 +774,11 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_slots);
     hipFree(ctx->d_desc);
     hipFree(ctx->d_ctr);
+    hipFree(ctx->ring.od);
+    hipFree(ctx->ring.dt);
+    hipFree(ctx->ring.tl);
+    hipFree(ctx->ring.ia);
+    hipFree(ctx->ring_px);
     free_queues(ctx);
     hipHostFree(ctx->h_done);
     hipEventDestroy(ctx->ev0);
@@ -986,7 +1159,7 @@ static int check_ready(mpt_ctx* ctx, const mpt_render_params* p) {
     if ((uint32_t)ctx->u.screenSize[0] != ctx->W || (uint32_t)ctx->u.screenSize[1] != ctx->H)
         return fail(ctx, MPT_ERR_INVALID_ARG, "uniforms.screenSize does not match mpt_resize");
     if (p->rng_mode < 0 || p->rng_mode > 1 || p->bsdf_mode < 0 || p->bsdf_mode > 1 || p->max_depth < 1 ||
-        p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 1 || p->shard_count < 1 || p->shard_rank < 0 ||
+        p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 2 || p->shard_count < 1 || p->shard_rank < 0 ||
         p->shard_rank >= p->shard_count)
         return fail(ctx, MPT_ERR_INVALID_ARG, "bad render params");
     return MPT_OK;
@@ -1043,16 +1216,13 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     pp.host_done = dev_done;
     if (pass_paths == 0) return MPT_OK;
 
-    const bool count = count_flag(p);
     const size_t lds = (size_t)ctx->n_lds_nodes * 32 + MPT_LDS_EXTRA;
     int per_cu = 0;
-    if (p->pipeline == MPT_PIPE_MEGAKERNEL) {
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, count_flag(p) ? (const void*)k_megakernel<true> : (const void*)k_megakernel<false>, ctx->wg_size, lds));
-    } else {
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, count_flag(p) ? (const void*)k_step<true> : (const void*)k_step<false>, ctx->wg_size, lds));
-    }
+    const bool all_lds = ctx->n_lds_nodes == ctx->n_nodes;
+    const void* kfun = p->pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
+                       : p->pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
+                                                          : step_kernel(count_flag(p), all_lds);
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfun, ctx->wg_size, lds));
     if (per_cu < 1) return fail(ctx, MPT_ERR_HIP, "kernel does not fit on a CU");
     if (ctx->wgs_per_cu > 0 && per_cu > ctx->wgs_per_cu) per_cu = ctx->wgs_per_cu;
     const int grid = ctx->prop.multiProcessorCount * per_cu;
@@ -1060,18 +1230,36 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     *ctx->h_done = 0;
     hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, ctx->d_desc, ctx->d_ctr, (uint32_t)pass_paths, slots_items,
                        (volatile uint32_t*)dev_done);
-    if (p->pipeline == MPT_PIPE_MEGAKERNEL) {
+    if (p->pipeline == MPT_PIPE_MEGAKERNEL || p->pipeline == MPT_PIPE_WAVELOCAL) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (time_kernels) {
             HIPCHK(hipEventCreate(&e0));
             HIPCHK(hipEventCreate(&e1));
             HIPCHK(hipEventRecord(e0, st));
         }
-        if (count)
-            hipLaunchKernelGGL(k_megakernel<true>, dim3(grid), dim3(ctx->wg_size), lds, st, pp);
-        else
-            hipLaunchKernelGGL(k_megakernel<false>, dim3(grid), dim3(ctx->wg_size), lds, st, pp);
-        HIPCHK(hipGetLastError());
+        if (p->pipeline == MPT_PIPE_WAVELOCAL) {
+            const size_t waves = (size_t)grid * (ctx->wg_size / 64);
+            if (waves > ctx->ring_waves) {
+                hipFree(ctx->ring.od); hipFree(ctx->ring.dt); hipFree(ctx->ring.tl); hipFree(ctx->ring.ia);
+                hipFree(ctx->ring_px);
+                ctx->ring = QueueDev{};
+                ctx->ring_px = nullptr;
+                ctx->ring_waves = 0;
+                const size_t n = waves * MPT_WL_RING;
+                HIPCHK(hipMalloc(&ctx->ring.od, n * 16));
+                HIPCHK(hipMalloc(&ctx->ring.dt, n * 16));
+                HIPCHK(hipMalloc(&ctx->ring.tl, n * 16));
+                HIPCHK(hipMalloc(&ctx->ring.ia, n * 8));
+                HIPCHK(hipMalloc(&ctx->ring_px, n * 8));
+                ctx->ring_waves = waves;
+            }
+            uint32_t wl_block = ctx->wl_block;
+            void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&ctx->ring_px, (void*)&wl_block};
+            HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
+        } else {
+            void* args[] = {(void*)&pp};
+            HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
+        }
         if (time_kernels) {
             HIPCHK(hipEventRecord(e1, st));
             HIPCHK(hipEventSynchronize(e1));
@@ -1115,10 +1303,10 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
                 if (!e0 || !e1) return fail(ctx, MPT_ERR_HIP, "hipEventCreate failed");
                 HIPCHK(hipEventRecord(e0, st));
             }
-            if (count)
-                hipLaunchKernelGGL(k_step<true>, dim3(grid), dim3(ctx->wg_size), lds, st, pp, parity);
-            else
-                hipLaunchKernelGGL(k_step<false>, dim3(grid), dim3(ctx->wg_size), lds, st, pp, parity);
+            {
+                void* args[] = {(void*)&pp, (void*)&parity};
+                HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
+            }
             if (time_kernels) {
                 HIPCHK(hipEventRecord(e1, st));
                 timed.emplace_back(e0, e1);

@@ -43,7 +43,7 @@ def test_oracle_reproduces_golden(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 @pytest.mark.parametrize("name", sorted(MANIFEST))
 def test_hip_reproduces_golden(gpu_ctx, name, pipeline):
     from metalpathtracer_amd import capi, host

@@ -87,7 +87,7 @@ def test_closest_hit_matches_oracle_bitwise(gpu_ctx):
     assert hits > 1000
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 @pytest.mark.parametrize("name,W,H,cam,depth,spp,bsdf", [
     ("scene.xml", 160, 90, None, 8, 8, 0),
     ("scene.xml", 101, 67, None, 32, 4, 0),       # ragged size: partial 8x8 tiles on both edges
@@ -129,7 +129,7 @@ def test_small_wavefront_width_and_sample_ranges(gpu_ctx):
     np.testing.assert_array_equal(whole.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_literal_frame_protocol(gpu_ctx, pipeline):
     """The reference's actual per-frame behaviour (stuck RNG, running mean, frameCount off-by-one):
     4 frames, host-seeded randomSeed, against the oracle's frame protocol."""
@@ -272,9 +272,10 @@ def test_full_size_properties(gpu_ctx):
     gpu_ctx.clear_sum()
     gpu_ctx.render(sample_count=4, **kw)
     np.testing.assert_array_equal(a.view(np.uint32), gpu_ctx.read_sum().view(np.uint32))       # deterministic
-    gpu_ctx.clear_sum()
-    gpu_ctx.render(sample_count=4, pipeline=capi.PIPE_MEGAKERNEL, **kw)
-    np.testing.assert_array_equal(a.view(np.uint32), gpu_ctx.read_sum().view(np.uint32))       # pipelines agree
+    for pipe in (capi.PIPE_WAVEFRONT, capi.PIPE_MEGAKERNEL, capi.PIPE_WAVELOCAL):
+        gpu_ctx.clear_sum()
+        gpu_ctx.render(sample_count=4, pipeline=pipe, **kw)
+        np.testing.assert_array_equal(a.view(np.uint32), gpu_ctx.read_sum().view(np.uint32))   # pipelines agree
     gpu_ctx.clear_sum()
     gpu_ctx.render(sample_begin=0, sample_count=1, **kw)
     gpu_ctx.render(sample_begin=1, sample_count=3, **kw)

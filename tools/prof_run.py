@@ -1,0 +1,17 @@
+"""Minimal driver for rocprofv3 runs: scene.xml 1080p, SPP samples, one pipeline (scratch tool)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metalpathtracer_amd import capi, host
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+scene = os.environ.get("SCENE", "scene.xml")
+sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", scene), sc); assert st == 0
+sc.buildBVH(int(os.environ.get("BVH", "0")))
+ctx = capi.Context(0); ctx.upload_scene(*sc.buffers())
+W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
+ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
+spp = int(os.environ.get("SPP", "16")); pipe = int(os.environ.get("PIPE", "1")); depth = int(os.environ.get("DEPTH", "8"))
+for rep in range(int(os.environ.get("REPS", "2"))):
+    ctx.clear_sum(); ctx.reset_stats()
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=depth, sample_count=spp, pipeline=pipe, slots_per_iter=int(os.environ.get("SLOTS", "0")))
+    st = ctx.stats()
+    print("pipe %d spp %d depth %d: total_ms %.2f trace_ms %.2f launches %d rays %d -> %.1f Mrays/s" % (pipe, spp, depth, st["total_ms"], st["trace_kernel_ms"], st["trace_launches"], st["rays"], st["rays"] / st["total_ms"] / 1e3), flush=True)
