@@ -86,6 +86,11 @@ typedef struct mpt_stats {   /* cumulative since mpt_reset_stats                
     double trace_kernel_ms;  /* HIP-event time of the trace/shade kernels of the last mpt_render      */
     double total_ms;         /* HIP-event time of the whole last mpt_render (all kernels, its stream) */
     uint64_t trace_launches; /* trace/shade kernel launches in the last mpt_render                    */
+    /* divergence diagnostics (only with MPT_FLAG_COUNT_WORK): loop trips per WAVE; 64 x trips = issued lane
+     * slots, so node_visits / (64 * wave_node_iters) is the lane utilisation of the box-test loop            */
+    uint64_t wave_node_iters;   /* box-test loop trips                                                        */
+    uint64_t wave_prim_iters;   /* primitive-test loop trips                                                  */
+    uint64_t wave_leaf_phases;  /* leaf phases entered                                                        */
 } mpt_stats;
 
 /* Device selection / lifetime.  Replaces MTL::CreateSystemDefaultDevice + Renderer::Renderer /

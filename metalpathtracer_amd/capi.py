@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmpt_hip.so")
+LIB_PATH = os.environ.get("MPT_LIB") or os.path.join(_PKG, "lib", "libmpt_hip.so")
 
 RNG_LITERAL, RNG_PHILOX = 0, 1
 BSDF_LAMBERT, BSDF_SCATTER = 0, 1
@@ -70,6 +70,7 @@ class Stats(C.Structure):
         ("paths", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64), ("aabb_hits", C.c_uint64),
         ("prim_tests", C.c_uint64), ("iterations", C.c_uint64),
         ("trace_kernel_ms", C.c_double), ("total_ms", C.c_double), ("trace_launches", C.c_uint64),
+        ("wave_node_iters", C.c_uint64), ("wave_prim_iters", C.c_uint64), ("wave_leaf_phases", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -114,8 +114,25 @@ struct SceneDev {
     uint32_t n_mats;
 };
 
+// true in exactly one lane of the currently active lanes (used to count wave-level loop trips)
+__device__ __forceinline__ bool first_active_lane() {
+    const uint32_t me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return me == (uint32_t)__builtin_amdgcn_readfirstlane((int)me);
+}
+
+// max of a value over the active lanes of the wave (values here are small trip counts)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)v, off);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
 struct WorkCount {
-    uint32_t node_visits, aabb_hits, prim_tests;
+    uint32_t node_visits, aabb_hits, prim_tests;   // per lane (== the oracle's counters when summed)
+    uint32_t node_iters, prim_iters, outer_iters;  // per WAVE loop trips (lane 0 only): x64 = issued lane slots
 };
 
 // Primitives of one leaf, in index order — PathTracing.h:106-186.
@@ -125,7 +142,10 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, uint32_t first, ui
     for (uint32_t k = 0; k < count; ++k) {
         const float4 p0 = sc.prims[3 * (first + k)];
         const float4 p1 = sc.prims[3 * (first + k) + 1];
-        if (COUNT) wc.prim_tests++;
+        if (COUNT) {
+            wc.prim_tests++;
+            if (first_active_lane()) wc.prim_iters++;
+        }
         const int ptype = (int)p0.w;
         if (ptype == 1) {  // PathTracing.h:143-176 Moeller-Trumbore, two-sided
             const float4 p2 = sc.prims[3 * (first + k) + 2];
@@ -175,22 +195,22 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, uint32_t first, ui
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) v4f* LdsNodes;
 
-template <bool COUNT, bool ALL_LDS>
-__device__ __forceinline__ void closest_hit(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d,
-                                            float& best_t, int& best_prim, WorkCount& wc) {
+// Resumable closest hit with a wave-level budget of box-test loop trips.
+//   in/out: node (next node to visit, 0 = root), best_t, best_prim  (fresh query: 0, +inf, -1)
+//   returns true when the traversal is complete, false when the budget ran out first (node/best_* then hold the
+//   exact state to resume from: the ray sees the same sequence of tests either way, so results do not change).
+// "while-while" form: every lane first walks box tests until IT has a leaf to test (or is done); only then does the
+// wave run the primitive loop, for all lanes with a pending leaf at once.
+template <bool COUNT, bool ALL_LDS, bool BUDGETED>
+__device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d, uint32_t& node,
+                                                   float& best_t, int& best_prim, uint32_t budget, WorkCount& wc) {
     const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;  // PathTracing.h:61 (per call there)
-    best_t = INFINITY;
-    best_prim = -1;
-    uint32_t i = 0;
+    uint32_t i = node;
     const uint32_t n_nodes = sc.n_nodes, n_lds = sc.n_lds_nodes;
-    // "while-while" form: every lane first walks box tests until IT has a leaf to test (or is done); only then
-    // does the wave run the primitive loop, for all lanes with a pending leaf at once.  A lane performs exactly
-    // the same sequence of box and primitive tests as the straightforward loop (same order, same best_t at each
-    // test), so the result is unchanged; what changes is that the long primitive loop is no longer executed for
-    // one or two lanes every time any lane reaches a leaf.
+    uint32_t trips = 0;  // trips of the box-test loop this wave has made (kept equal in all lanes, see below)
     for (;;) {
         uint32_t leaf_first = 0, leaf_count = 0;
-        while (i < n_nodes) {
+        while (i < n_nodes && (!BUDGETED || trips < budget)) {
             float4 n0, n1;
             if (ALL_LDS || i < n_lds) {
                 const v4f a = lds_nodes[2 * i], b = lds_nodes[2 * i + 1];
@@ -218,7 +238,9 @@ __device__ __forceinline__ void closest_hit(const SceneDev& sc, LdsNodes lds_nod
             if (COUNT) {
                 wc.node_visits++;
                 wc.aabb_hits += box ? 1u : 0u;
+                if (first_active_lane()) wc.node_iters++;
             }
+            if (BUDGETED) trips++;
             if (B >= 0) {
                 i = box ? (uint32_t)A : (uint32_t)B;
             } else {
@@ -231,9 +253,26 @@ __device__ __forceinline__ void closest_hit(const SceneDev& sc, LdsNodes lds_nod
                 }
             }
         }
-        if (leaf_count == 0u) break;
-        leaf_test<COUNT>(sc, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
+        // a lane that left the loop early (leaf found / done) adopts the trips the rest of the wave made meanwhile
+        if (BUDGETED) trips = wave_max_u32(trips);
+        if (leaf_count != 0u) {
+            if (COUNT && first_active_lane()) wc.outer_iters++;
+            leaf_test<COUNT>(sc, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
+        }
+        // the wave goes round again only while some lane still has nodes to visit and budget is left
+        if (__ballot(i < n_nodes && (!BUDGETED || trips < budget)) == 0ull) break;
     }
+    node = i;
+    return i >= n_nodes;
+}
+
+template <bool COUNT, bool ALL_LDS>
+__device__ __forceinline__ void closest_hit(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d,
+                                            float& best_t, int& best_prim, WorkCount& wc) {
+    uint32_t node = 0;
+    best_t = INFINITY;
+    best_prim = -1;
+    closest_hit_resume<COUNT, ALL_LDS, false>(sc, lds_nodes, o, d, node, best_t, best_prim, 0xFFFFFFFFu, wc);
 }
 
 struct HitInfo {

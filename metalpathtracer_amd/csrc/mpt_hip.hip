@@ -57,7 +57,7 @@ struct PassDesc {
     uint32_t next_path, total_paths;
     uint32_t slots_items;  // wavefront width in 64-slot items
     uint32_t done, overflow, iterations;
-    unsigned long long paths, rays, node_visits, aabb_hits, prim_tests;
+    unsigned long long paths, rays, node_visits, aabb_hits, prim_tests, node_iters, prim_iters, leaf_phases;
 };
 
 // Atomic counters live on lines of their own (MPT_CTR_STRIDE words apart): device-scope atomics are
@@ -84,6 +84,28 @@ struct PassParams {
     ShadeParams sp;
     volatile uint32_t* host_done;
 };
+
+// per-wave statistics: reduce over the 64 lanes, one atomic per counter per wave
+template <bool COUNT>
+__device__ __forceinline__ void flush_stats(PassDesc* desc, uint32_t n_rays, uint32_t n_paths, const WorkCount& wc) {
+    unsigned long long v[8] = {n_rays, n_paths, wc.node_visits, wc.aabb_hits, wc.prim_tests,
+                               wc.node_iters, wc.prim_iters, wc.outer_iters};
+    const int n = COUNT ? 8 : 2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= n) break;
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        unsigned long long* dst[8] = {&desc->rays, &desc->paths, &desc->node_visits, &desc->aabb_hits,
+                                      &desc->prim_tests, &desc->node_iters, &desc->prim_iters, &desc->leaf_phases};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= n) break;
+            if (v[k]) atomicAdd(dst[k], v[k]);
+        }
+    }
+}
 
 // path index -> pixel.  path = ((tile_local * S) + s) * 64 + lane; a wave = one 8x8 pixel tile.
 __device__ __forceinline__ bool path_to_pixel(const PassParams& pp, uint32_t path, uint32_t& px, uint32_t& py,
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uin
     const uint32_t total_paths = desc->total_paths;
     const uint32_t regen_base = desc->regen_base;
     uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0};
+    WorkCount wc = {0, 0, 0, 0, 0, 0};
 
     const uint32_t waves_per_group = (gridDim.x * (blockDim.x >> 6) + MPT_NGROUP - 1) / MPT_NGROUP;
     uint32_t item = 0, item_last = 0;
@@ -268,29 +290,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uin
             }
         }
     }
-    // per-wave statistics: reduce over lanes, one atomic per counter per wave
-    unsigned long long r = n_rays, p = n_paths;
-    for (int off = 32; off > 0; off >>= 1) {
-        r += __shfl_down(r, off);
-        p += __shfl_down(p, off);
-    }
-    if (COUNT) {
-        unsigned long long a = wc.node_visits, b = wc.aabb_hits, c = wc.prim_tests;
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_down(a, off);
-            b += __shfl_down(b, off);
-            c += __shfl_down(c, off);
-        }
-        if (lane == 0) {
-            atomicAdd(&desc->node_visits, a);
-            atomicAdd(&desc->aabb_hits, b);
-            atomicAdd(&desc->prim_tests, c);
-        }
-    }
-    if (lane == 0 && (r | p)) {
-        atomicAdd(&desc->rays, r);
-        atomicAdd(&desc->paths, p);
-    }
+    flush_stats<COUNT>(desc, n_rays, n_paths, wc);
 }
 
 // one wave; lane 0 does the (tiny) serial work
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams p
     const uint32_t total_paths = pp.desc->total_paths;
     const uint32_t waves_per_block = blockDim.x >> 6;
     uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0};
+    WorkCount wc = {0, 0, 0, 0, 0, 0};
     for (uint32_t chunk = blockIdx.x * waves_per_block + (threadIdx.x >> 6); chunk * 64u < total_paths;
          chunk += gridDim.x * waves_per_block) {
         PathState ps;
@@ -367,43 +367,43 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams p
         }
         pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
     }
-    unsigned long long r = n_rays, p = n_paths, a = wc.node_visits, b = wc.aabb_hits, c = wc.prim_tests;
-    for (int off = 32; off > 0; off >>= 1) {
-        r += __shfl_down(r, off);
-        p += __shfl_down(p, off);
-        if (COUNT) {
-            a += __shfl_down(a, off);
-            b += __shfl_down(b, off);
-            c += __shfl_down(c, off);
-        }
-    }
-    if (lane == 0) {
-        atomicAdd(&pp.desc->rays, r);
-        atomicAdd(&pp.desc->paths, p);
-        if (COUNT) {
-            atomicAdd(&pp.desc->node_visits, a);
-            atomicAdd(&pp.desc->aabb_hits, b);
-            atomicAdd(&pp.desc->prim_tests, c);
-        }
-    }
+    flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
+}
+
+__device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
 // Wave-local wavefront (MPT_PIPE_WAVELOCAL): the wavefront idea at wave scope.
-// Every persistent wave owns a private ring of 128 ray records (SoA, 16-byte fields, in global memory but
-// touched by this wave only, so it lives in L2) and alternates between two kinds of full-width steps:
-//   * ring holds >= 64 bounce rays  -> pop 64 of them, closest hit, one bounce of shading
-//   * otherwise                     -> take the next 8x8-pixel tile sample (64 new paths), generate the primary
-//                                      rays in registers, closest hit, one bounce of shading
-// Survivors of either step are compacted with a wave64 ballot + mbcnt prefix and appended to the ring.  Compared
-// with the global wavefront there is no kernel boundary, no shared counter and no atomic per step (the ring's
-// head and count are wave-uniform registers); compared with the megakernel every step runs with (nearly) all 64
-// lanes on rays of the same generation, instead of a tail of few long paths.  Path ids are handed out 1024 at a
-// time from the pass cursor (one atomic per 16 tile samples).
-#define MPT_WL_RING 128u
-#define MPT_WL_BLOCK 4096u  // upper bound of a claim
+// Every persistent wave owns two private rings of ray records (SoA, 16-byte fields, in global memory but touched
+// by this wave only, so they live in L2) and alternates between full-width steps:
+//   heavy ring holds >= 64 rays -> pop 64 parked rays, resume their closest-hit queries without a budget, shade
+//   light ring holds >= 64 rays -> pop 64 fresh bounce rays, closest hit with a BUDGET of box-test loop trips, shade
+//                                  the rays that finished; rays still traversing are PARKED in the heavy ring
+//                                  together with their exact traversal state (next node, best t, best primitive)
+//   otherwise                   -> take the next 8x8-pixel tile sample (64 new paths), generate the primary rays in
+//                                  registers, closest hit, one bounce of shading
+// Survivors of any step are compacted with a wave64 ballot + mbcnt prefix and appended to the light ring.
+// Why the budget: bounce rays are bimodal on this kind of scene — 88 % need <= 8 box tests, 10 % need 30-160 (they
+// cross the mesh) — and a wave runs as long as its slowest lane: a full wave of bounce rays used only 14 % of its
+// box-test lane slots.  Parking sorts rays by remaining work, so light steps are short and heavy steps are dense.
+// A parked ray resumes with exactly the state it stopped with, so it sees the same sequence of tests: results are
+// bit-identical.  Compared with the global wavefront there is no kernel boundary, no shared counter and no atomic
+// per step (ring heads and counts are wave-uniform registers).  Path ids are claimed from the pass cursor by guided
+// self-scheduling (one atomic per claim).
+#define MPT_WL_RING 256u       // records per ring (light and heavy each); occupancy stays below 192, see below
+#define MPT_WL_BLOCK 4096u     // upper bound of a path-id claim
+struct WaveRings {             // [n_waves][2 rings][MPT_WL_RING]
+    float4* od;                // (o.xyz, d.x)
+    float4* dt;                // (d.y, d.z, thr.r, thr.g)
+    float4* tl;                // (thr.b, L.rgb)
+    uint4* ia;                 // (path | bounce << 27, L.a bits, pixel, sample)
+    uint4* tv;                 // heavy ring only: (next node, best t bits, best primitive, 0)
+};
+
 template <bool COUNT, bool ALL_LDS>
-__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp, QueueDev ring, uint2* ring_px,
-                                                                 uint32_t wl_block) {
+__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp, WaveRings ring, uint32_t wl_block,
+                                                                 uint32_t light_budget) {
     extern __shared__ float4 lds_nodes_raw[];
     stage_nodes(pp.scene, lds_nodes_raw);
     const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
@@ -411,67 +411,58 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
     const uint32_t total_paths = pp.desc->total_paths;
     uint32_t* cursor = &pp.ctr[MPT_CTR_CURSOR(0)];
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t rbase = wave_id * MPT_WL_RING;
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    uint32_t head = 0, count = 0;  // wave-uniform ring state
+    const uint32_t lbase = wave_id * (2u * MPT_WL_RING), hbase = lbase + MPT_WL_RING;
+    const uint32_t M = MPT_WL_RING - 1u;
+    uint32_t l_head = 0, l_cnt = 0, h_head = 0, h_cnt = 0;  // wave-uniform ring state
     uint32_t cur = 0, end = 0;     // wave-uniform private range of path ids (multiples of 64)
     uint32_t seen = 0;             // cursor value at this wave's previous claim
     bool exhausted = false;
     uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0};
+    WorkCount wc = {0, 0, 0, 0, 0, 0};
     for (;;) {
+        // Step choice.  Light steps come first: they never grow the light ring (64 out, <= 64 survivors in) and add
+        // <= 64 to the heavy ring; heavy and primary steps run only while the light ring holds < 64 and add <= 64 to
+        // it.  So light <= 127 and heavy <= 63 + 2 * 64 = 191 at any time: both fit MPT_WL_RING = 256.
+        int kind;  // 0 primary, 1 light, 2 heavy
+        if (l_cnt >= 64u) kind = 1;
+        else if (h_cnt >= 64u) kind = 2;
+        else {
+            if (!exhausted && cur == end) {
+                // guided self-scheduling on the pass cursor: claim remaining / (8 * waves) path ids, rounded to whole
+                // 64-path tile samples and clamped to [64, wl_block]: few atomics while there is plenty of work, fine
+                // grain at the end of the pass (tile samples differ ~5x in cost between sky and geometry).  `seen` is
+                // the cursor value of this wave's previous claim: an extra load of the hot cursor line before the
+                // atomic made the kernel 4x slower (loads of a line under atomic fire serialise at the memory side).
+                uint32_t k = 0, blk = 0;
+                if (lane == 0) {
+                    const uint32_t left = seen < total_paths ? total_paths - seen : 0u;
+                    blk = (left / (8u * n_waves)) & ~63u;
+                    blk = blk < 64u ? 64u : (blk > wl_block ? wl_block : blk);
+                    k = atomicAdd(cursor, blk);
+                }
+                k = __builtin_amdgcn_readfirstlane(k);
+                blk = __builtin_amdgcn_readfirstlane(blk);
+                seen = k;
+                if (k >= total_paths) {
+                    exhausted = true;
+                } else {
+                    cur = k;
+                    end = (k + blk < total_paths) ? k + blk : total_paths;
+                }
+            }
+            if (!exhausted) kind = 0;
+            else if (l_cnt > 0u) kind = 1;   // drain what is left with partial waves
+            else if (h_cnt > 0u) kind = 2;
+            else break;
+        }
         PathState ps;
         PathRngDev g;
         bool valid = false;
-        bool from_ring = count >= 64u;
-        if (!from_ring && !exhausted && cur == end) {
-            // guided self-scheduling on the pass cursor: claim remaining / (8 * waves) path ids, rounded to whole
-            // 64-path tile samples and clamped to [64, wl_block]: few atomics while there is plenty of work, fine
-            // grain at the end of the pass (tile samples differ ~5x in cost between sky and geometry)
-            uint32_t k = 0, blk = 0;
-            if (lane == 0) {
-                // `seen` = the cursor value this wave saw at its previous claim (no extra load of the hot line)
-                const uint32_t left = seen < total_paths ? total_paths - seen : 0u;
-                blk = (left / (8u * n_waves)) & ~63u;
-                blk = blk < 64u ? 64u : (blk > wl_block ? wl_block : blk);
-                k = atomicAdd(cursor, blk);
-            }
-            k = __builtin_amdgcn_readfirstlane(k);
-            blk = __builtin_amdgcn_readfirstlane(blk);
-            seen = k;
-            if (k >= total_paths) {
-                exhausted = true;
-            } else {
-                cur = k;
-                end = (k + blk < total_paths) ? k + blk : total_paths;
-            }
-        }
-        if (!from_ring && exhausted) {
-            if (count == 0u) break;
-            from_ring = true;  // drain what is left with a partial wave
-        }
-        if (from_ring) {
-            const uint32_t n = count < 64u ? count : 64u;
-            if (lane < n) {
-                const uint32_t at = rbase + ((head + lane) & (MPT_WL_RING - 1u));
-                const float4 a = ring.od[at], b = ring.dt[at], c = ring.tl[at];
-                const uint2 ia = ring.ia[at], pxs = ring_px[at];
-                ps.o = f3(a.x, a.y, a.z);
-                ps.d = f3(a.w, b.x, b.y);
-                ps.thr = f3(b.z, b.w, c.x);
-                ps.L = f3(c.y, c.z, c.w);
-                ps.La = __uint_as_float(ia.y);
-                ps.path = ia.x & 0x07FFFFFFu;
-                ps.bounce = ia.x >> 27;
-                g.pixel = pxs.x;
-                g.sample = pxs.y;
-                g.lit_seed = 0;
-                if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
-                valid = true;
-            }
-            head = (head + n) & (MPT_WL_RING - 1u);
-            count -= n;
-        } else {
+        uint32_t node = 0;
+        float best_t = INFINITY;
+        int best_prim = -1;
+        if (kind == 0) {
             ps.path = cur + lane;
             cur += 64u;
             uint32_t px, py, sidx;
@@ -480,51 +471,83 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                 valid = true;
                 n_paths++;
             }
+        } else {
+            const uint32_t cnt = kind == 1 ? l_cnt : h_cnt;
+            const uint32_t n = cnt < 64u ? cnt : 64u;
+            if (lane < n) {
+                const uint32_t at = kind == 1 ? lbase + ((l_head + lane) & M) : hbase + ((h_head + lane) & M);
+                const float4 a = ring.od[at], b = ring.dt[at], c = ring.tl[at];
+                const uint4 ia = ring.ia[at];
+                ps.o = f3(a.x, a.y, a.z);
+                ps.d = f3(a.w, b.x, b.y);
+                ps.thr = f3(b.z, b.w, c.x);
+                ps.L = f3(c.y, c.z, c.w);
+                ps.La = __uint_as_float(ia.y);
+                ps.path = ia.x & 0x07FFFFFFu;
+                ps.bounce = ia.x >> 27;
+                g.pixel = ia.z;
+                g.sample = ia.w;
+                g.lit_seed = 0;
+                if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+                if (kind == 2) {
+                    const uint4 tv = ring.tv[at];
+                    node = tv.x;
+                    best_t = __uint_as_float(tv.y);
+                    best_prim = (int)tv.z;
+                }
+                valid = true;
+            }
+            if (kind == 1) {
+                l_head = (l_head + n) & M;
+                l_cnt -= n;
+            } else {
+                h_head = (h_head + n) & M;
+                h_cnt -= n;
+            }
         }
-        bool alive = false;
+        bool alive = false, parked = false;
         if (valid) {
-            float t;
-            int prim;
-            closest_hit<COUNT, ALL_LDS>(pp.scene, lds_nodes, ps.o, ps.d, t, prim, wc);
-            n_rays++;
-            alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
-            if (!alive)
-                pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+            bool done;
+            if (kind == 1)
+                done = closest_hit_resume<COUNT, ALL_LDS, true>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
+                                                               light_budget, wc);
+            else
+                done = closest_hit_resume<COUNT, ALL_LDS, false>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
+                                                                0xFFFFFFFFu, wc);
+            if (kind != 2) n_rays++;  // a resumed query was counted when it started
+            if (done) {
+                alive = shade_bounce(pp.scene, pp.sp, g, ps, best_t, best_prim);
+                if (!alive)
+                    pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+            } else {
+                parked = true;
+            }
         }
-        const unsigned long long mask = __ballot(alive);
-        if (mask != 0ull) {
+        const unsigned long long am = __ballot(alive), pm = __ballot(parked);
+        if (am != 0ull) {  // survivors -> light ring
             if (alive) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t at = rbase + ((head + count + rank) & (MPT_WL_RING - 1u));
+                const uint32_t at = lbase + ((l_head + l_cnt + wave_rank(am)) & M);
                 ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
                 ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
                 ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint2(ps.path | (ps.bounce << 27), __float_as_uint(ps.La));
-                ring_px[at] = make_uint2(g.pixel, g.sample);
+                ring.ia[at] = make_uint4(ps.path | (ps.bounce << 27), __float_as_uint(ps.La), g.pixel, g.sample);
             }
-            count += (uint32_t)__popcll(mask);
+            l_cnt += (uint32_t)__popcll(am);
         }
-    }
-    unsigned long long r = n_rays, p = n_paths, a = wc.node_visits, b = wc.aabb_hits, c = wc.prim_tests;
-    for (int off = 32; off > 0; off >>= 1) {
-        r += __shfl_down(r, off);
-        p += __shfl_down(p, off);
-        if (COUNT) {
-            a += __shfl_down(a, off);
-            b += __shfl_down(b, off);
-            c += __shfl_down(c, off);
+        if (pm != 0ull) {  // unfinished queries -> heavy ring, with their traversal state
+            if (parked) {
+                const uint32_t at = hbase + ((h_head + h_cnt + wave_rank(pm)) & M);
+                ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+                ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+                ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+                ring.ia[at] = make_uint4(ps.path | (ps.bounce << 27), __float_as_uint(ps.La), g.pixel, g.sample);
+                ring.tv[at] = make_uint4(node, __float_as_uint(best_t), (uint32_t)best_prim, 0u);
+            }
+            h_cnt += (uint32_t)__popcll(pm);
         }
+        if (l_cnt > MPT_WL_RING || h_cnt > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (see step choice)
     }
-    if (lane == 0) {
-        atomicAdd(&pp.desc->rays, r);
-        atomicAdd(&pp.desc->paths, p);
-        if (COUNT) {
-            atomicAdd(&pp.desc->node_visits, a);
-            atomicAdd(&pp.desc->aabb_hits, b);
-            atomicAdd(&pp.desc->prim_tests, c);
-        }
-    }
+    flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
 }
 
 // sum[pixel] += sum over the pass's samples (in sample order) of the clamped per-sample colour
@@ -576,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_trace_rays(SceneDev sc, const float* o
     F3 ro = f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     float t;
     int prim;
-    WorkCount wc = {0, 0, 0};
+    WorkCount wc = {0, 0, 0, 0, 0, 0};
     closest_hit<false, false>(sc, (LdsNodes)lds_nodes, ro, rd, t, prim, wc);
     t_out[i] = t;
     if (prim >= 0) {
@@ -653,9 +676,9 @@ struct mpt_ctx {
     // launch geometry
     int wg_size = 1024;
     bool time_kernels = true;
-    QueueDev ring = {};        // wave-local wavefront: private rings, MPT_WL_RING records per wave
-    uint2* ring_px = nullptr;
+    WaveRings ring = {};       // wave-local wavefront: private light + heavy rings, MPT_WL_RING records each
     size_t ring_waves = 0;
+    uint32_t light_budget = 12;  // box-test loop trips a fresh bounce ray gets before it is parked
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
     size_t lds_budget = 60 * 1024;
@@ -735,6 +758,7 @@ extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_LDS_BYTES"))) ctx->lds_budget = (size_t)atol(e);
     ctx->time_kernels = !((e = getenv("MPT_NO_KERNEL_EVENTS")) && atoi(e));
     if ((e = getenv("MPT_WL_BLOCK")) && atoi(e) >= 64) ctx->wl_block = (uint32_t)atoi(e) & ~63u;
+    if ((e = getenv("MPT_LIGHT_BUDGET")) && atoi(e) >= 1) ctx->light_budget = (uint32_t)atoi(e);
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 1024;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
@@ -778,7 +802,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->ring.dt);
     hipFree(ctx->ring.tl);
     hipFree(ctx->ring.ia);
-    hipFree(ctx->ring_px);
+    hipFree(ctx->ring.tv);
     free_queues(ctx);
     hipHostFree(ctx->h_done);
     hipEventDestroy(ctx->ev0);
@@ -1215,6 +1239,8 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     HIPCHK(hipHostGetDevicePointer((void**)&dev_done, ctx->h_done, 0));
     pp.host_done = dev_done;
     if (pass_paths == 0) return MPT_OK;
+    // test mode: poison the per-path result slots so that a path that is lost shows up as NaN in the image
+    if (count_flag(p)) HIPCHK(hipMemsetAsync(ctx->d_slots, 0xFF, pass_paths * 16, ctx->stream));
 
     const size_t lds = (size_t)ctx->n_lds_nodes * 32 + MPT_LDS_EXTRA;
     int per_cu = 0;
@@ -1240,21 +1266,20 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
         if (p->pipeline == MPT_PIPE_WAVELOCAL) {
             const size_t waves = (size_t)grid * (ctx->wg_size / 64);
             if (waves > ctx->ring_waves) {
-                hipFree(ctx->ring.od); hipFree(ctx->ring.dt); hipFree(ctx->ring.tl); hipFree(ctx->ring.ia);
-                hipFree(ctx->ring_px);
-                ctx->ring = QueueDev{};
-                ctx->ring_px = nullptr;
+                WaveRings& r = ctx->ring;
+                hipFree(r.od); hipFree(r.dt); hipFree(r.tl); hipFree(r.ia); hipFree(r.tv);
+                r = WaveRings{};
                 ctx->ring_waves = 0;
-                const size_t n = waves * MPT_WL_RING;
-                HIPCHK(hipMalloc(&ctx->ring.od, n * 16));
-                HIPCHK(hipMalloc(&ctx->ring.dt, n * 16));
-                HIPCHK(hipMalloc(&ctx->ring.tl, n * 16));
-                HIPCHK(hipMalloc(&ctx->ring.ia, n * 8));
-                HIPCHK(hipMalloc(&ctx->ring_px, n * 8));
+                const size_t n = waves * 2 * MPT_WL_RING;
+                HIPCHK(hipMalloc(&r.od, n * 16));
+                HIPCHK(hipMalloc(&r.dt, n * 16));
+                HIPCHK(hipMalloc(&r.tl, n * 16));
+                HIPCHK(hipMalloc(&r.ia, n * 16));
+                HIPCHK(hipMalloc(&r.tv, n * 16));
                 ctx->ring_waves = waves;
             }
-            uint32_t wl_block = ctx->wl_block;
-            void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&ctx->ring_px, (void*)&wl_block};
+            uint32_t wl_block = ctx->wl_block, budget = ctx->light_budget;
+            void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&wl_block, (void*)&budget};
             HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
         } else {
             void* args[] = {(void*)&pp};
@@ -1342,13 +1367,17 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
 static int collect_pass_stats(mpt_ctx* ctx) {
     PassDesc hd;
     HIPCHK(hipMemcpy(&hd, ctx->d_desc, sizeof hd, hipMemcpyDeviceToHost));
+    if (hd.overflow) return fail(ctx, MPT_ERR_OVERFLOW, "ray ring overflow");
     ctx->stats.paths += hd.paths;
     ctx->stats.rays += hd.rays;
     ctx->stats.node_visits += hd.node_visits;
     ctx->stats.aabb_hits += hd.aabb_hits;
     ctx->stats.prim_tests += hd.prim_tests;
+    ctx->stats.wave_node_iters += hd.node_iters;
+    ctx->stats.wave_prim_iters += hd.prim_iters;
+    ctx->stats.wave_leaf_phases += hd.leaf_phases;
     ctx->stats.iterations += hd.iterations;
-    HIPCHK(hipMemsetAsync(&ctx->d_desc->paths, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(&ctx->d_desc->paths, 0, 8 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(&ctx->d_desc->iterations, 0, 4, ctx->stream));
     return MPT_OK;
 }

@@ -601,6 +601,11 @@ struct Hit {  // Structs.h:12-20
     int primitiveId;
     int isTriangle;
 };
+// Diagnostic histogram of BVH node visits per ray (bins 0..255, last bin = 255+), split primary / bounce.
+// Filled only when enabled (orc_histogram_enable); used to size the GPU pipeline's traversal budgets.
+static uint64_t g_hist[2][256];
+static bool g_hist_on = false;
+
 struct Counters {
     uint64_t rays, node_pops, aabb_pass, prim_tests, sphere_tests, tri_tests, pushes, misses, bounces, emissive_hits,
         depth_exhausted, paths;
@@ -784,7 +789,12 @@ static void ray_color(Ray r, const float* bvh, const float* prims, const float* 
     int depth = 0;
     for (; depth < maxDepth; ++depth) {
         ct->rays++;
+        const uint64_t pops_before = ct->node_pops;
         Hit hit = first_hit_bvh(r, bvh, prims, primIdx, ct);
+        if (g_hist_on) {
+            uint64_t n = ct->node_pops - pops_before;
+            __atomic_fetch_add(&g_hist[depth == 0 ? 0 : 1][n > 255 ? 255 : n], 1, __ATOMIC_RELAXED);
+        }
         if (hit.primitiveId == -1) {  // PathTracing.h:225-232
             V3 ud = normalize(r.d);
             float t = 0.5f * (ud.y + 1.0f);
@@ -1101,6 +1111,12 @@ void orc_first_hit(const float o[3], const float d[3], const float* bvh, const f
     normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z;
     *frontFace = h.frontFace ? 1 : 0;
 }
+
+void orc_histogram_enable(int on) {
+    g_hist_on = on != 0;
+    if (on) memset(g_hist, 0, sizeof g_hist);
+}
+void orc_histogram_read(uint64_t* out512) { memcpy(out512, g_hist, sizeof g_hist); }
 
 // FNV-1a 64 over a byte range (image hashes).
 uint64_t orc_fnv1a64(const void* data, uint64_t nbytes) {

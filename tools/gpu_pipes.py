@@ -18,7 +18,7 @@ for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,8,32").split(",")]:
     for pipe in pipes:
         for rep in range(2):
             ctx.clear_sum(); ctx.reset_stats()
-            ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=depth, sample_count=spp, pipeline=pipe)
+            ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=depth, sample_count=spp, pipeline=pipe, flags=int(os.environ.get("FLAGS","0")))
             st = ctx.stats()
         img = ctx.read_sum()
         same = "" if ref is None else ("same" if np.array_equal(img.view(np.uint32), ref.view(np.uint32)) else "DIFFERENT")

@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in rows:
         n = r['Kernel_Name']
-        if any(k in n for k in ('k_mega', 'k_wavelocal', 'k_step')):
+        if any(k in n for k in ('k_mega', 'k_wavelocal', 'k_step', 'k_stream')):
             agg[(n.split('(')[0][-30:], r['Dispatch_Id'])][r['Counter_Name']] += float(r['Counter_Value'])
     last = {}
     for (n, did), v in agg.items(): last[n] = v
