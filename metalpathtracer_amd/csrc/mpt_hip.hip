@@ -80,6 +80,8 @@ struct PassParams {
     float W, H;
     uint32_t width, height, tiles_x;
     uint32_t S, sample_begin;    // samples per pixel in this pass, first sample index
+    uint32_t s_shift;            // log2(S) when S is a power of two, else 0xFF
+    const uint32_t* tile_xy;     // this rank's tiles in processing order: x | y << 16
     uint32_t rank, nranks;
     ShadeParams sp;
     volatile uint32_t* host_done;
@@ -108,15 +110,23 @@ __device__ __forceinline__ void flush_stats(PassDesc* desc, uint32_t n_rays, uin
 }
 
 // path index -> pixel.  path = ((tile_local * S) + s) * 64 + lane; a wave = one 8x8 pixel tile.
+// tile_xy[tile_local] = tile x | tile y << 16 of this rank's tile_local-th tile: the host lays the rank's tiles out
+// in a strided (low-discrepancy) order so that any window of consecutive path ids mixes cheap (sky) and expensive
+// (mesh) tiles — with row-major order the expensive tiles cluster and the end of a pass is all slow work.
 __device__ __forceinline__ bool path_to_pixel(const PassParams& pp, uint32_t path, uint32_t& px, uint32_t& py,
                                               uint32_t& s) {
-    uint32_t lane = path & 63u, chunk = path >> 6;
-    uint32_t tl = chunk / pp.S;
-    s = chunk - tl * pp.S;
-    uint32_t T = tl * pp.nranks + pp.rank;
-    uint32_t ty = T / pp.tiles_x, tx = T - ty * pp.tiles_x;
-    px = tx * 8u + (lane & 7u);
-    py = ty * 8u + (lane >> 3);
+    const uint32_t lane = path & 63u, chunk = path >> 6;
+    uint32_t tl;
+    if (pp.s_shift != 0xFFu) {  // samples per pass is a power of two (the usual case): no division
+        tl = chunk >> pp.s_shift;
+        s = chunk & (pp.S - 1u);
+    } else {
+        tl = chunk / pp.S;
+        s = chunk - tl * pp.S;
+    }
+    const uint32_t xy = pp.tile_xy[tl];
+    px = (xy & 0xFFFFu) * 8u + (lane & 7u);
+    py = (xy >> 16) * 8u + (lane >> 3);
     return px < pp.width && py < pp.height;
 }
 
@@ -392,7 +402,7 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 // per step (ring heads and counts are wave-uniform registers).  Path ids are claimed from the pass cursor by guided
 // self-scheduling (one atomic per claim).
 #define MPT_WL_RING 256u       // records per ring (light and heavy each); occupancy stays below 192, see below
-#define MPT_WL_BLOCK 4096u     // upper bound of a path-id claim
+#define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
 struct WaveRings {             // [n_waves][2 rings][MPT_WL_RING]
     float4* od;                // (o.xyz, d.x)
     float4* dt;                // (d.y, d.z, thr.r, thr.g)
@@ -403,7 +413,7 @@ struct WaveRings {             // [n_waves][2 rings][MPT_WL_RING]
 
 template <bool COUNT, bool ALL_LDS>
 __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp, WaveRings ring, uint32_t wl_block,
-                                                                 uint32_t light_budget) {
+                                                                 uint32_t light_budget, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_nodes_raw[];
     stage_nodes(pp.scene, lds_nodes_raw);
     const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
@@ -429,16 +439,17 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
         else if (h_cnt >= 64u) kind = 2;
         else {
             if (!exhausted && cur == end) {
-                // guided self-scheduling on the pass cursor: claim remaining / (8 * waves) path ids, rounded to whole
-                // 64-path tile samples and clamped to [64, wl_block]: few atomics while there is plenty of work, fine
-                // grain at the end of the pass (tile samples differ ~5x in cost between sky and geometry).  `seen` is
+                // guided self-scheduling on the pass cursor: claim remaining / (wl_div * waves) path ids, rounded to whole
+                // 64-path tile samples and clamped to [wl_min, wl_block]: few atomics while there is plenty of work,
+                // fine grain at the end of the pass (tile samples differ ~5x in cost between sky and geometry; with
+                // remaining/(2*waves) the last wave finished 23 ms after the first, with /16 within ~1-2 ms).  `seen` is
                 // the cursor value of this wave's previous claim: an extra load of the hot cursor line before the
                 // atomic made the kernel 4x slower (loads of a line under atomic fire serialise at the memory side).
                 uint32_t k = 0, blk = 0;
                 if (lane == 0) {
                     const uint32_t left = seen < total_paths ? total_paths - seen : 0u;
-                    blk = (left / (8u * n_waves)) & ~63u;
-                    blk = blk < 64u ? 64u : (blk > wl_block ? wl_block : blk);
+                    blk = (left / (wl_div * n_waves)) & ~63u;
+                    blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
                     k = atomicAdd(cursor, blk);
                 }
                 k = __builtin_amdgcn_readfirstlane(k);
@@ -659,6 +670,11 @@ struct mpt_ctx {
     int cur_target = 0;
     float4* d_sum_own = nullptr;
     float4* d_sum = nullptr;
+    // this rank's tile processing order (x | y << 16), rebuilt when size or sharding changes
+    uint32_t* d_tile_xy = nullptr;
+    uint32_t tile_W = 0, tile_H = 0, tile_rank = 0, tile_nranks = 0, tile_count = 0;
+    int tile_order_mode = 0;  // 0 row-major top-down (measured best with guided claims: the cheap sky tiles take the
+                              // large early claims, the expensive tiles the small late ones), 1 strided, 2 bottom-up
     // literal RNG seeds
     uint32_t* d_pixel_seed = nullptr;
     float seed_rs[3] = {NAN, NAN, NAN};
@@ -679,6 +695,7 @@ struct mpt_ctx {
     WaveRings ring = {};       // wave-local wavefront: private light + heavy rings, MPT_WL_RING records each
     size_t ring_waves = 0;
     uint32_t light_budget = 12;  // box-test loop trips a fresh bounce ray gets before it is parked
+    uint32_t wl_min = 64, wl_div = 16;  // guided path-id claims: max(wl_min, remaining / (wl_div * waves))
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
     size_t lds_budget = 60 * 1024;
@@ -759,6 +776,9 @@ extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
     ctx->time_kernels = !((e = getenv("MPT_NO_KERNEL_EVENTS")) && atoi(e));
     if ((e = getenv("MPT_WL_BLOCK")) && atoi(e) >= 64) ctx->wl_block = (uint32_t)atoi(e) & ~63u;
     if ((e = getenv("MPT_LIGHT_BUDGET")) && atoi(e) >= 1) ctx->light_budget = (uint32_t)atoi(e);
+    if ((e = getenv("MPT_WL_MIN")) && atoi(e) >= 64) ctx->wl_min = (uint32_t)atoi(e) & ~63u;
+    if ((e = getenv("MPT_TILE_ORDER"))) ctx->tile_order_mode = atoi(e);
+    if ((e = getenv("MPT_WL_DIV")) && atoi(e) >= 1) ctx->wl_div = (uint32_t)atoi(e);
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 1024;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
@@ -795,6 +815,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_accum[1]);
     hipFree(ctx->d_sum_own);
     hipFree(ctx->d_pixel_seed);
+    hipFree(ctx->d_tile_xy);
     hipFree(ctx->d_slots);
     hipFree(ctx->d_desc);
     hipFree(ctx->d_ctr);
@@ -1154,6 +1175,46 @@ static int ensure_pixel_seeds(mpt_ctx* ctx) {
     return MPT_OK;
 }
 
+// Tiles t with t % nranks == rank, in the order the pass walks them.  Strided order: local index k -> local tile
+// (k * P) mod n with P ~ 0.618 n coprime to n, which spreads consecutive path-id windows over the whole image.
+static int ensure_tile_order(mpt_ctx* ctx, uint32_t rank, uint32_t nranks, uint32_t& n_local) {
+    const uint32_t tiles_x = (ctx->W + 7) / 8, tiles_y = (ctx->H + 7) / 8, tiles = tiles_x * tiles_y;
+    n_local = tiles > rank ? (tiles - rank + nranks - 1) / nranks : 0;
+    if (ctx->d_tile_xy && ctx->tile_W == ctx->W && ctx->tile_H == ctx->H && ctx->tile_rank == rank &&
+        ctx->tile_nranks == nranks)
+        return MPT_OK;
+    std::vector<uint32_t> xy(std::max<uint32_t>(n_local, 1));
+    uint64_t P = 1;
+    if (ctx->tile_order_mode == 1 && n_local > 2) {
+        P = (uint64_t)(0.6180339887 * n_local) | 1ull;
+        auto gcd = [](uint64_t a, uint64_t b) {
+            while (b) {
+                uint64_t t = a % b;
+                a = b;
+                b = t;
+            }
+            return a;
+        };
+        while (gcd(P, n_local) != 1) P += 2;
+    }
+    for (uint32_t k = 0; k < n_local; ++k) {
+        uint32_t tl = (uint32_t)(((uint64_t)k * P) % n_local);
+        if (ctx->tile_order_mode == 2) tl = n_local - 1u - k;  // bottom-up row-major
+        const uint32_t T = tl * nranks + rank;
+        xy[k] = (T % tiles_x) | ((T / tiles_x) << 16);
+    }
+    hipFree(ctx->d_tile_xy);
+    ctx->d_tile_xy = nullptr;
+    HIPCHK(hipMalloc(&ctx->d_tile_xy, xy.size() * 4));
+    HIPCHK(hipMemcpy(ctx->d_tile_xy, xy.data(), xy.size() * 4, hipMemcpyHostToDevice));
+    ctx->tile_W = ctx->W;
+    ctx->tile_H = ctx->H;
+    ctx->tile_rank = rank;
+    ctx->tile_nranks = nranks;
+    ctx->tile_count = n_local;
+    return MPT_OK;
+}
+
 static int ensure_workspace(mpt_ctx* ctx, uint32_t slots_items, uint64_t pass_paths) {
     uint32_t cap = ((slots_items + MPT_NSHARD - 1) / MPT_NSHARD + 2) * 64u;
     if (cap > ctx->shard_cap) {
@@ -1194,9 +1255,12 @@ static inline bool count_flag(const mpt_render_params* p) { return (p->flags & M
 // Runs one pass of S samples/pixel over this rank's tiles; leaves the per-path results in d_slots.
 static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_begin, uint32_t S, PassParams& pp,
                     uint32_t& n_local_tiles, bool time_kernels) {
-    const uint32_t tiles_x = (ctx->W + 7) / 8, tiles_y = (ctx->H + 7) / 8, tiles = tiles_x * tiles_y;
+    const uint32_t tiles_x = (ctx->W + 7) / 8;
     const uint32_t nr = (uint32_t)p->shard_count, rk = (uint32_t)p->shard_rank;
-    n_local_tiles = tiles > rk ? (tiles - rk + nr - 1) / nr : 0;
+    {
+        int trc = ensure_tile_order(ctx, rk, nr, n_local_tiles);
+        if (trc) return trc;
+    }
     const uint64_t pass_paths = (uint64_t)n_local_tiles * S * 64ull;
     if (pass_paths >= (1ull << 27)) return fail(ctx, MPT_ERR_INVALID_ARG, "pass too large (internal)");
     uint32_t slots = p->slots_per_iter ? p->slots_per_iter : (16u << 20);
@@ -1226,6 +1290,8 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     pp.height = ctx->H;
     pp.tiles_x = tiles_x;
     pp.S = S;
+    pp.s_shift = (S & (S - 1)) == 0 ? (uint32_t)__builtin_ctz(S) : 0xFFu;
+    pp.tile_xy = ctx->d_tile_xy;
     pp.sample_begin = sample_begin;
     pp.rank = rk;
     pp.nranks = nr;
@@ -1238,6 +1304,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     uint32_t* dev_done = nullptr;
     HIPCHK(hipHostGetDevicePointer((void**)&dev_done, ctx->h_done, 0));
     pp.host_done = dev_done;
+
     if (pass_paths == 0) return MPT_OK;
     // test mode: poison the per-path result slots so that a path that is lost shows up as NaN in the image
     if (count_flag(p)) HIPCHK(hipMemsetAsync(ctx->d_slots, 0xFF, pass_paths * 16, ctx->stream));
@@ -1278,8 +1345,8 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
                 HIPCHK(hipMalloc(&r.tv, n * 16));
                 ctx->ring_waves = waves;
             }
-            uint32_t wl_block = ctx->wl_block, budget = ctx->light_budget;
-            void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&wl_block, (void*)&budget};
+            uint32_t wl_block = ctx->wl_block, budget = ctx->light_budget, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
+            void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&wl_block, (void*)&budget, (void*)&wl_min, (void*)&wl_div};
             HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
         } else {
             void* args[] = {(void*)&pp};
