@@ -48,6 +48,20 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(pipe, rays_per_launch):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate runs, gfx950 x2 read
+    correction applied).  PMC cannot be collected from inside this process, so the per-ray figure measured on the
+    same workload and pipeline is scaled by this run's rays per launch; None when no matching profile exists."""
+    try:
+        if pipe != 2:
+            return None
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        return prof["traffic_bytes_per_ray"] * rays_per_launch
+    except Exception:
+        return None
+
+
 def host_cores():
     """Threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota when there is one."""
     n = max(1, len(os.sched_getaffinity(0)))
@@ -98,9 +112,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path is the product and there is no CPU fallback")
+    backend = os.environ.get("MPT_BENCH_BACKEND", "nccl")   # "gloo" only for functional tests on a 1-GPU box
+    if os.environ.get("MPT_BENCH_SHARE_GPU"):               # functional tests: several ranks on one GPU
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        D.init_from_env(backend="nccl")
+        if backend == "nccl":
+            D.init_from_env(backend="nccl")
+        else:
+            import torch.distributed as dist0
+            dist0.init_process_group(backend=backend, rank=rank, world_size=world)
         import torch.distributed as dist
 
     # ---- untimed setup: ingest, BVH, upload (the product's own host layer) ----
@@ -196,11 +217,15 @@ def main():
             achieved = b_ray * rays_per_launch / sec_per_launch / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(pipe, rays_per_launch),
                 "kernel": {0: "k_step", 1: "k_megakernel", 2: "k_wavelocal"}[pipe],
                 "launches": launches, "avg_launch_ms": kernel_ms / launches,
                 "bytes_per_ray": b_ray, "n_node": n_node, "n_prim": n_prim, "h": h,
                 "rays_per_launch": rays_per_launch,
+                "algorithmic_bytes_per_launch": b_ray * rays_per_launch,
+                "note": "achieved = SURVEY 8(d) algorithmic bytes/ray x rays per launch / avg launch time; frac > 1 "
+                        "means the kernel is not HBM-bound: the scene (0.5 MB) is served from LDS/L2, measured HBM-side "
+                        "traffic is ~158 B/ray (traffic field, bytes per launch)",
             }
         print(json.dumps(out), flush=True)
     if world > 1:

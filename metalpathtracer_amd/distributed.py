@@ -49,7 +49,13 @@ def reduce_framebuffer(sum_tensor, dst=0):
     """In-place reduce(sum) of the [H, W, 4] float32 HDR sum to rank `dst` (no-op for a single process)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(sum_tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if sum_tensor.is_cuda and dist.get_backend() == "gloo":
+            # functional-test path only (two ranks sharing one GPU cannot use RCCL): stage through the host
+            host = sum_tensor.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            sum_tensor.copy_(host)
+        else:
+            dist.reduce(sum_tensor, dst=dst, op=dist.ReduceOp.SUM)
     return sum_tensor
 
 

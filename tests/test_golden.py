@@ -73,3 +73,18 @@ def test_hip_reproduces_golden(gpu_ctx, name, pipeline):
         c = m["counters"]
         assert (st["paths"], st["rays"], st["node_visits"], st["aabb_hits"], st["prim_tests"]) == (
             c["paths"], c["rays"], c["node_pops"], c["aabb_pass"], c["prim_tests"])
+
+
+def test_cornell_config0_cpu_plumbing():
+    """BASELINE.json configs[0] on the CPU only (no GPU): Cornell box 256x256, 16 spp through the oracle — finite,
+    lit, red wall on the left / green on the right, sky visible through the open front."""
+    from conftest import CORNELL_CAM
+    sc, buf = oracle_scene("cornell.xml")
+    assert sc.prim_count == 12 and sc.triangle_count == 10
+    u = ob.make_uniforms(256, 256, sc.prim_count, sc.triangle_count, cam=CORNELL_CAM)
+    img, ct = ob.render(u, buf, rng_mode=ob.RNG_PHILOX, max_depth=32, accumulate=1, sample_count=16, seed=(1, 0), threads=8)
+    img = img / 16
+    assert np.isfinite(img).all() and ct["paths"] == 256 * 256 * 16
+    left, right = img[100:180, 20:50, :3].mean((0, 1)), img[100:180, 206:236, :3].mean((0, 1))
+    assert left[0] > 2 * left[1] and right[1] > 2 * right[0]      # red wall / green wall
+    assert ct["emissive_hits"] > 0 and ct["misses"] > 0

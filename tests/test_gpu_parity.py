@@ -292,3 +292,67 @@ def test_full_size_properties(gpu_ctx):
     ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, max_depth=8, accumulate=1, sample_count=4, seed=(1, 0), out=ref,
               rows=band)
     np.testing.assert_array_equal(a[band[0]:band[1]].view(np.uint32), ref[band[0]:band[1]].view(np.uint32))
+
+
+@pytest.mark.parametrize("budget", ["1", "3", "1000000"])
+def test_parking_budgets_do_not_change_results(budget, monkeypatch):
+    """Wave-local pipeline: a fresh bounce ray gets `budget` box-test loop trips before it is parked with its
+    traversal state and resumed later.  A tiny budget parks almost every ray (and resumes it from the saved node /
+    best t / best primitive); results and work counters must not move."""
+    from metalpathtracer_amd import capi, host
+    monkeypatch.setenv("MPT_LIGHT_BUDGET", budget)
+    ctx = capi.Context(0)
+    sc, buf = host_scene("scene.xml")
+    ctx.upload_scene(*buf)
+    W, H, spp = 192, 108, 6   # 6 spp: samples-per-pass not a power of two (division path of path -> pixel)
+    u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount())
+    ctx.resize(W, H)
+    ctx.set_uniforms(u)
+    ctx.clear_sum()
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=32, sample_count=spp, seed=(5, 5), pipeline=capi.PIPE_WAVELOCAL,
+               flags=capi.FLAG_COUNT_WORK)
+    got = ctx.read_sum()
+    st = ctx.stats()
+    ref, ct = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG_PHILOX, max_depth=32, accumulate=1,
+                        sample_count=spp, seed=(5, 5), threads=8)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert (st["paths"], st["rays"], st["node_visits"], st["aabb_hits"], st["prim_tests"]) == (
+        ct["paths"], ct["rays"], ct["node_pops"], ct["aabb_pass"], ct["prim_tests"])
+    ctx.close()
+
+
+def test_cornell_config0_matches_cpu_reference_path(gpu_ctx):
+    """BASELINE.json configs[0]: Cornell box, 256x256, 16 spp — the CPU path (oracle) and the HIP path agree."""
+    from metalpathtracer_amd import capi
+    buf, uo = setup(gpu_ctx, "cornell.xml", 256, 256, cam=CORNELL_CAM)
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=32, sample_count=16, seed=(1, 0))
+    got = gpu_ctx.read_sum()
+    ref, ct = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, max_depth=32, accumulate=1, sample_count=16, seed=(1, 0), threads=8)
+    assert pixel_l2(got / 16, ref / 16) < L2_TOL
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert ct["paths"] == 256 * 256 * 16
+
+
+def test_flat_leaf_box_is_never_hit(gpu_ctx):
+    """Reference quirk (PathTracing.h:68 `tMax <= tMin`): an axis-aligned flat quad alone in a leaf has a
+    zero-thickness box and is culled by the slab test — for the oracle and the device alike."""
+    from metalpathtracer_amd import host
+    sc = host.Scene()
+    o = ob.OracleScene()
+    for tri in (((-1, 2, 1), (1, 2, 1), (1, 2, -1)), ((-1, 2, 1), (1, 2, -1), (-1, 2, -1))):
+        sc.addTriangle(*tri)
+        o.add_triangle(*tri)
+    sc.buildBVH()
+    o.build_bvh()
+    buf = sc.buffers()
+    gpu_ctx.upload_scene(*buf)
+    org = np.array([[0, 0, 0], [0.3, 0, 0.2], [0, 4, 0]], np.float32)
+    d = np.array([[0, 1, 0], [0, 1, 0], [0, -1, 0]], np.float32)
+    t, prim, _, _ = gpu_ctx.trace_rays(org, d)
+    assert (prim == -1).all() and np.isinf(t).all()
+    for i in range(3):
+        assert ob.first_hit(org[i], d[i], o.buffers())[1] == -1
+    # a slightly oblique ray has a non-degenerate slab interval on x/z but still a zero one on y: also missed
+    t, prim, _, _ = gpu_ctx.trace_rays(np.array([[0, 0, 0]], np.float32), np.array([[0.1, 1, 0.05]], np.float32))
+    assert prim[0] == -1 and ob.first_hit((0, 0, 0), (0.1, 1, 0.05), o.buffers())[1] == -1

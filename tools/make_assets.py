@@ -27,7 +27,10 @@ def main():
     quad_obj("cornell_back.obj", [(-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1)])
     quad_obj("cornell_left.obj", [(-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1)])
     quad_obj("cornell_right.obj", [(1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)])
-    quad_obj("cornell_light.obj", [(-0.35, 1.98, 0.35), (0.35, 1.98, 0.35), (0.35, 1.98, -0.35), (-0.35, 1.98, -0.35)])
+    # The light is tilted by 1 mm on purpose: the reference's slab test rejects a box when tMax <= tMin
+    # (PathTracing.h:68), so an axis-aligned flat quad that ends up alone in a BVH leaf (zero-thickness box) can
+    # never be hit — faithfully reproduced by the oracle and the HIP path (see DESIGN.md "Reference quirks").
+    quad_obj("cornell_light.obj", [(-0.35, 1.98, 0.35), (0.35, 1.98, 0.35), (0.35, 1.979, -0.35), (-0.35, 1.979, -0.35)])
     with open(os.path.join(ROOT, "cornell.xml"), "w") as f:
         f.write("""<Scene>
     <!-- Cornell-style box in the reference schema (SURVEY.md 8d config 1). Open front/top: misses see the sky. -->
