@@ -5,10 +5,10 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over the whole 1920x1080 frame at --spp-per-step samples per pixel
-(default 64; the default K = 4 steps is exactly the 256 spp of the headline config).  Scene load, BVH build and
-upload happen before the timed region (inputs resident in HBM); the timed region holds the K render steps and,
-for N > 1, the one RCCL reduce of the HDR framebuffer.  N > 1: one process per GPU, the 8x8 pixel tiles are
+A "step" is one pass of the hot path over the whole 1920x1080 frame at --spp-per-step samples per pixel (default
+256 = the headline config: one step is one complete 1920x1080x256spp render, a single kernel launch per GPU).  Scene
+load, BVH build and upload happen before the timed region (inputs resident in HBM); the timed region holds the K render
+steps and, for N > 1, the one RCCL reduce of the HDR framebuffer (the K steps accumulate into one HDR sum).  N > 1: one process per GPU, the 8x8 pixel tiles are
 interleaved over the ranks (strong scaling: the job is fixed, `value` = all rays of the job / max-over-ranks time).
 
 Rank 0 prints ONE JSON line.  Extra objects:
@@ -33,9 +33,9 @@ PIPE_NAMES = {0: "wavefront (global SoA queues)", 1: "megakernel", 2: "wave-loca
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
@@ -198,8 +198,8 @@ def main():
             "dtype": "f32",
             "data": "assets/scene.xml (the reference's bundled scene, mesh path remapped) — no dataset involved",
             "config": {
-                "workload": "scene.xml %dx%d, %d spp (%d steps x %d), depth %d" % (W, H, args.steps * spp, args.steps,
-                                                                                  spp, args.depth),
+                "workload": "scene.xml %dx%d x %d spp per step, depth %d (%d steps timed)" % (W, H, spp, args.depth,
+                                                                                           args.steps),
                 "prims": P, "bvh_nodes": sc.getBVHNodeCount(), "rng": "philox4x32-10 (pixel,sample,bounce)",
                 "pipeline": PIPE_NAMES[pipe],
                 "parallelism": "8x8-tile interleave over %d rank(s)%s" % (world, " + 1 RCCL reduce(sum) of the HDR framebuffer" if world > 1 else ""),

@@ -140,15 +140,17 @@ template <bool COUNT>
 __device__ __forceinline__ void leaf_test(const SceneDev& sc, uint32_t first, uint32_t count, F3 o, F3 d,
                                           float& best_t, int& best_prim, WorkCount& wc) {
     for (uint32_t k = 0; k < count; ++k) {
+        // the three 16-byte loads of a primitive are issued together (the third is used by triangles only, but a
+        // load that waits for the type check costs a second L2 round trip per primitive)
         const float4 p0 = sc.prims[3 * (first + k)];
         const float4 p1 = sc.prims[3 * (first + k) + 1];
+        const float4 p2 = sc.prims[3 * (first + k) + 2];
         if (COUNT) {
             wc.prim_tests++;
             if (first_active_lane()) wc.prim_iters++;
         }
         const int ptype = (int)p0.w;
         if (ptype == 1) {  // PathTracing.h:143-176 Moeller-Trumbore, two-sided
-            const float4 p2 = sc.prims[3 * (first + k) + 2];
             F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
             F3 h = cross3(d, e2);
             float a = dot3(e1, h);

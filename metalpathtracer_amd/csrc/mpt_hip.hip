@@ -384,36 +384,42 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Wave-local wavefront (MPT_PIPE_WAVELOCAL): the wavefront idea at wave scope.
-// Every persistent wave owns two private rings of ray records (SoA, 16-byte fields, in global memory but touched
-// by this wave only, so they live in L2) and alternates between full-width steps:
-//   heavy ring holds >= 64 rays -> pop 64 parked rays, resume their closest-hit queries without a budget, shade
-//   light ring holds >= 64 rays -> pop 64 fresh bounce rays, closest hit with a BUDGET of box-test loop trips, shade
-//                                  the rays that finished; rays still traversing are PARKED in the heavy ring
-//                                  together with their exact traversal state (next node, best t, best primitive)
-//   otherwise                   -> take the next 8x8-pixel tile sample (64 new paths), generate the primary rays in
-//                                  registers, closest hit, one bounce of shading
-// Survivors of any step are compacted with a wave64 ballot + mbcnt prefix and appended to the light ring.
-// Why the budget: bounce rays are bimodal on this kind of scene — 88 % need <= 8 box tests, 10 % need 30-160 (they
-// cross the mesh) — and a wave runs as long as its slowest lane: a full wave of bounce rays used only 14 % of its
-// box-test lane slots.  Parking sorts rays by remaining work, so light steps are short and heavy steps are dense.
-// A parked ray resumes with exactly the state it stopped with, so it sees the same sequence of tests: results are
-// bit-identical.  Compared with the global wavefront there is no kernel boundary, no shared counter and no atomic
-// per step (ring heads and counts are wave-uniform registers).  Path ids are claimed from the pass cursor by guided
-// self-scheduling (one atomic per claim).
-#define MPT_WL_RING 256u       // records per ring (light and heavy each); occupancy stays below 192, see below
+// Wave-local wavefront (MPT_PIPE_WAVELOCAL): the wavefront idea at wave scope, with rays sorted by remaining work.
+// Every persistent wave owns MPT_WL_LEVELS private rings of ray records (SoA, 16-byte fields, in global memory but
+// touched by this wave only) and runs full-width steps:
+//   ring k holds >= 64 rays -> pop 64, continue their closest-hit queries for at most budget[k] box-test loop trips,
+//                              shade the rays that finished (survivors are fresh rays -> ring 0), and PARK the rays
+//                              that are still traversing in ring k+1 with their exact traversal state (next node,
+//                              best t, best primitive).  The last ring has no budget.  Deepest ready ring first.
+//   no ring is ready        -> take the next 8x8-pixel tile sample (64 new paths), generate the primary rays in
+//                              registers, closest hit, one bounce of shading; survivors -> ring 0
+// Compaction into the rings is a wave64 ballot + mbcnt prefix; ring heads and counts are wave-uniform registers: no
+// kernel boundary, no shared counter, no atomic per step.
+// Why budgets: a wave runs as long as its slowest lane, and bounce rays are heavy-tailed on this kind of scene — 88 %
+// need <= 8 box tests, 10 % need 30-160 (they cross the mesh): a full wave of bounce rays used only 14 % of its
+// box-test lane slots.  Budgets 8/24/72/inf sort rays by remaining work (a radix sort on log3 of the work), so every
+// step runs rays of similar length (measured: box-test lane slots per ray 37.8 -> 17.8, VALU instructions per ray
+// 40 -> 24).  A parked ray resumes with exactly the state it stopped with and sees the
+// same sequence of tests: results are bit-identical.
+// Capacity: steps on rings never increase the total number of queued rays (64 out, <= 64 in) and a primary step
+// (+<= 64) runs only when every ring holds < 64, so the total never exceeds 64 * LEVELS + 64 = 384 < MPT_WL_RING.
+#define MPT_WL_LEVELS 5u
+#define MPT_WL_RING 512u       // records per ring
 #define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
-struct WaveRings {             // [n_waves][2 rings][MPT_WL_RING]
+struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING]
     float4* od;                // (o.xyz, d.x)
     float4* dt;                // (d.y, d.z, thr.r, thr.g)
     float4* tl;                // (thr.b, L.rgb)
-    uint4* ia;                 // (path | bounce << 27, L.a bits, pixel, sample)
-    uint4* tv;                 // heavy ring only: (next node, best t bits, best primitive, 0)
+    uint4* ia;                 // (path, L.a bits, pixel, sample | bounce << 27)   path ids use all 32 bits here
+    uint4* tv;                 // rings >= 1: (next node, best t bits, best primitive, 0)
+};
+struct WaveBudgets {
+    uint32_t b[MPT_WL_LEVELS]; // box-test loop trips granted per step of ring k (last entry unused: unlimited)
 };
 
 template <bool COUNT, bool ALL_LDS>
-__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp, WaveRings ring, uint32_t wl_block,
-                                                                 uint32_t light_budget, uint32_t wl_min, uint32_t wl_div) {
+__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp, WaveRings ring, WaveBudgets budgets,
+                                                                 uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_nodes_raw[];
     stage_nodes(pp.scene, lds_nodes_raw);
     const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
@@ -422,22 +428,27 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
     uint32_t* cursor = &pp.ctr[MPT_CTR_CURSOR(0)];
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t lbase = wave_id * (2u * MPT_WL_RING), hbase = lbase + MPT_WL_RING;
+    const uint32_t wbase = wave_id * (MPT_WL_LEVELS * MPT_WL_RING);
     const uint32_t M = MPT_WL_RING - 1u;
-    uint32_t l_head = 0, l_cnt = 0, h_head = 0, h_cnt = 0;  // wave-uniform ring state
+    uint32_t head[MPT_WL_LEVELS], cnt[MPT_WL_LEVELS];  // wave-uniform ring state (fully unrolled accesses)
+#pragma unroll
+    for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) head[k] = cnt[k] = 0;
     uint32_t cur = 0, end = 0;     // wave-uniform private range of path ids (multiples of 64)
     uint32_t seen = 0;             // cursor value at this wave's previous claim
     bool exhausted = false;
     uint32_t n_rays = 0, n_paths = 0;
     WorkCount wc = {0, 0, 0, 0, 0, 0};
+#ifdef MPT_DEBUG_WAVE_TIMES
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_exh = 0ull;
+#endif
     for (;;) {
-        // Step choice.  Light steps come first: they never grow the light ring (64 out, <= 64 survivors in) and add
-        // <= 64 to the heavy ring; heavy and primary steps run only while the light ring holds < 64 and add <= 64 to
-        // it.  So light <= 127 and heavy <= 63 + 2 * 64 = 191 at any time: both fit MPT_WL_RING = 256.
-        int kind;  // 0 primary, 1 light, 2 heavy
-        if (l_cnt >= 64u) kind = 1;
-        else if (h_cnt >= 64u) kind = 2;
-        else {
+        // ---- step choice: deepest ring with a full wave of rays; else new paths; else drain ----------------------
+        int level = -1;  // -1 = primary step
+#pragma unroll
+        for (int k = (int)MPT_WL_LEVELS - 1; k >= 0; --k)
+            if (level < 0 && cnt[k] >= 64u) level = k;
+        if (level < 0) {
             if (!exhausted && cur == end) {
                 // guided self-scheduling on the pass cursor: claim remaining / (wl_div * waves) path ids, rounded to whole
                 // 64-path tile samples and clamped to [wl_min, wl_block]: few atomics while there is plenty of work,
@@ -462,10 +473,16 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                     end = (k + blk < total_paths) ? k + blk : total_paths;
                 }
             }
-            if (!exhausted) kind = 0;
-            else if (l_cnt > 0u) kind = 1;   // drain what is left with partial waves
-            else if (h_cnt > 0u) kind = 2;
-            else break;
+            if (exhausted) {
+                // Drain: no new paths and no ring holds a full wave.  What is left in ALL rings is merged into
+                // full-width steps without a budget (deepest ring first), instead of one partial step per ring and
+                // bounce generation: with per-ring partial steps every wave spent 1.4-2.2 ms draining.
+                uint32_t total = 0;
+#pragma unroll
+                for (int k = 0; k < (int)MPT_WL_LEVELS; ++k) total += cnt[k];
+                if (total == 0u) break;
+                level = (int)MPT_WL_LEVELS;  // merged drain step
+            }
         }
         PathState ps;
         PathRngDev g;
@@ -473,7 +490,10 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
         uint32_t node = 0;
         float best_t = INFINITY;
         int best_prim = -1;
-        if (kind == 0) {
+        uint32_t budget = 0xFFFFFFFFu;
+        bool fresh = false;  // this lane starts a new closest-hit query (primary ray or ring-0 record)
+        if (level < 0) {
+            fresh = true;
             ps.path = cur + lane;
             cur += 64u;
             uint32_t px, py, sidx;
@@ -483,49 +503,63 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                 n_paths++;
             }
         } else {
-            const uint32_t cnt = kind == 1 ? l_cnt : h_cnt;
-            const uint32_t n = cnt < 64u ? cnt : 64u;
-            if (lane < n) {
-                const uint32_t at = kind == 1 ? lbase + ((l_head + lane) & M) : hbase + ((h_head + lane) & M);
-                const float4 a = ring.od[at], b = ring.dt[at], c = ring.tl[at];
+            // lanes -> ring records.  Normal step: 64 records of ring `level`.  Merged drain step: up to 64 records
+            // taken from all rings, deepest first (lane ranges [lo_k, lo_k + take_k) per ring).
+            uint32_t my_ring = 0, my_off = 0;
+            bool take = false;
+            uint32_t assigned = 0;
+#pragma unroll
+            for (int k = (int)MPT_WL_LEVELS - 1; k >= 0; --k) {
+                const bool use = (level == (int)MPT_WL_LEVELS) || (level == k);
+                uint32_t tk = use ? cnt[k] : 0u;
+                tk = tk < 64u - assigned ? tk : 64u - assigned;
+                if (lane >= assigned && lane < assigned + tk) {
+                    take = true;
+                    my_ring = (uint32_t)k;
+                    my_off = (head[k] + (lane - assigned)) & M;
+                }
+                if (level == k) budget = budgets.b[k];
+                head[k] = (head[k] + tk) & M;
+                cnt[k] -= tk;
+                assigned += tk;
+            }
+            if (take) {
+                const uint32_t at = wbase + my_ring * MPT_WL_RING + my_off;
+                const float4 a = ring.od[at], b = ring.dt[at], cc = ring.tl[at];
                 const uint4 ia = ring.ia[at];
                 ps.o = f3(a.x, a.y, a.z);
                 ps.d = f3(a.w, b.x, b.y);
-                ps.thr = f3(b.z, b.w, c.x);
-                ps.L = f3(c.y, c.z, c.w);
+                ps.thr = f3(b.z, b.w, cc.x);
+                ps.L = f3(cc.y, cc.z, cc.w);
                 ps.La = __uint_as_float(ia.y);
-                ps.path = ia.x & 0x07FFFFFFu;
-                ps.bounce = ia.x >> 27;
+                ps.path = ia.x;
+                ps.bounce = ia.w >> 27;
                 g.pixel = ia.z;
-                g.sample = ia.w;
+                g.sample = ia.w & 0x07FFFFFFu;
                 g.lit_seed = 0;
                 if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
-                if (kind == 2) {
+                if (my_ring > 0u) {
                     const uint4 tv = ring.tv[at];
                     node = tv.x;
                     best_t = __uint_as_float(tv.y);
                     best_prim = (int)tv.z;
+                } else {
+                    fresh = true;
                 }
                 valid = true;
             }
-            if (kind == 1) {
-                l_head = (l_head + n) & M;
-                l_cnt -= n;
-            } else {
-                h_head = (h_head + n) & M;
-                h_cnt -= n;
-            }
         }
+        const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS - 1;
         bool alive = false, parked = false;
         if (valid) {
             bool done;
-            if (kind == 1)
+            if (budgeted)
                 done = closest_hit_resume<COUNT, ALL_LDS, true>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
-                                                               light_budget, wc);
+                                                               budget, wc);
             else
                 done = closest_hit_resume<COUNT, ALL_LDS, false>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
                                                                 0xFFFFFFFFu, wc);
-            if (kind != 2) n_rays++;  // a resumed query was counted when it started
+            if (fresh) n_rays++;  // a resumed query was counted when it started
             if (done) {
                 alive = shade_bounce(pp.scene, pp.sp, g, ps, best_t, best_prim);
                 if (!alive)
@@ -535,29 +569,52 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
             }
         }
         const unsigned long long am = __ballot(alive), pm = __ballot(parked);
-        if (am != 0ull) {  // survivors -> light ring
+        if (am != 0ull) {  // survivors are fresh rays -> ring 0
             if (alive) {
-                const uint32_t at = lbase + ((l_head + l_cnt + wave_rank(am)) & M);
+                const uint32_t at = wbase + ((head[0] + cnt[0] + wave_rank(am)) & M);
                 ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
                 ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
                 ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint4(ps.path | (ps.bounce << 27), __float_as_uint(ps.La), g.pixel, g.sample);
+                ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
             }
-            l_cnt += (uint32_t)__popcll(am);
+            cnt[0] += (uint32_t)__popcll(am);
         }
-        if (pm != 0ull) {  // unfinished queries -> heavy ring, with their traversal state
+        if (pm != 0ull) {  // unfinished queries -> next ring, with their traversal state (only from budgeted steps)
+            uint32_t h = 0, c = 0;
+#pragma unroll
+            for (int k = 1; k < (int)MPT_WL_LEVELS; ++k)
+                if (k == level + 1) {
+                    h = head[k];
+                    c = cnt[k];
+                }
             if (parked) {
-                const uint32_t at = hbase + ((h_head + h_cnt + wave_rank(pm)) & M);
+                const uint32_t at = wbase + (uint32_t)(level + 1) * MPT_WL_RING + ((h + c + wave_rank(pm)) & M);
                 ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
                 ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
                 ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint4(ps.path | (ps.bounce << 27), __float_as_uint(ps.La), g.pixel, g.sample);
+                ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
                 ring.tv[at] = make_uint4(node, __float_as_uint(best_t), (uint32_t)best_prim, 0u);
             }
-            h_cnt += (uint32_t)__popcll(pm);
+#pragma unroll
+            for (int k = 1; k < (int)MPT_WL_LEVELS; ++k)
+                if (k == level + 1) cnt[k] = c + (uint32_t)__popcll(pm);
         }
-        if (l_cnt > MPT_WL_RING || h_cnt > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (see step choice)
+        uint32_t worst = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) worst = cnt[k] > worst ? cnt[k] : worst;
+        if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (see capacity note above)
+#ifdef MPT_DEBUG_WAVE_TIMES
+        if (exhausted && t_exh == 0ull) t_exh = __builtin_amdgcn_s_memrealtime();
+#endif
     }
+#ifdef MPT_DEBUG_WAVE_TIMES  // diagnostics build: per-wave (start, cursor exhausted, end) timestamps, 100 MHz ticks
+    if (lane == 0) {
+        unsigned long long* dbg = (unsigned long long*)(ring.tv + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING);
+        dbg[3 * wave_id] = t_start;
+        dbg[3 * wave_id + 1] = t_exh;
+        dbg[3 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
 }
 
@@ -694,7 +751,8 @@ struct mpt_ctx {
     bool time_kernels = true;
     WaveRings ring = {};       // wave-local wavefront: private light + heavy rings, MPT_WL_RING records each
     size_t ring_waves = 0;
-    uint32_t light_budget = 12;  // box-test loop trips a fresh bounce ray gets before it is parked
+    WaveBudgets budgets = {{8, 24, 72, 0x7FFFFFFF, 0}};  // box-test loop trips per step of ring 0..3 (measured best
+                                                        // ladder; an unlimited ring-3 budget leaves ring 4 unused)
     uint32_t wl_min = 64, wl_div = 16;  // guided path-id claims: max(wl_min, remaining / (wl_div * waves))
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
@@ -775,7 +833,18 @@ extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_LDS_BYTES"))) ctx->lds_budget = (size_t)atol(e);
     ctx->time_kernels = !((e = getenv("MPT_NO_KERNEL_EVENTS")) && atoi(e));
     if ((e = getenv("MPT_WL_BLOCK")) && atoi(e) >= 64) ctx->wl_block = (uint32_t)atoi(e) & ~63u;
-    if ((e = getenv("MPT_LIGHT_BUDGET")) && atoi(e) >= 1) ctx->light_budget = (uint32_t)atoi(e);
+    if ((e = getenv("MPT_BUDGETS"))) {  // e.g. "6,12,24,48"
+        unsigned v[4] = {6, 12, 24, 48};
+        int got = sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]);
+        for (int k = 0; k < 4; ++k) {
+            if (k >= got) v[k] = v[k - 1] * 2;
+            ctx->budgets.b[k] = v[k] < 1 ? 1 : v[k];
+        }
+    }
+    if ((e = getenv("MPT_LIGHT_BUDGET")) && atoi(e) >= 1) {  // one number: geometric ladder b, 2b, 4b, 8b
+        uint32_t b = (uint32_t)atoi(e);
+        for (int k = 0; k < 4; ++k) ctx->budgets.b[k] = b > (1u << 28) ? b : b << k;
+    }
     if ((e = getenv("MPT_WL_MIN")) && atoi(e) >= 64) ctx->wl_min = (uint32_t)atoi(e) & ~63u;
     if ((e = getenv("MPT_TILE_ORDER"))) ctx->tile_order_mode = atoi(e);
     if ((e = getenv("MPT_WL_DIV")) && atoi(e) >= 1) ctx->wl_div = (uint32_t)atoi(e);
@@ -1245,9 +1314,16 @@ static int check_ready(mpt_ctx* ctx, const mpt_render_params* p) {
         return fail(ctx, MPT_ERR_INVALID_ARG, "uniforms.screenSize does not match mpt_resize");
     if (p->rng_mode < 0 || p->rng_mode > 1 || p->bsdf_mode < 0 || p->bsdf_mode > 1 || p->max_depth < 1 ||
         p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 2 || p->shard_count < 1 || p->shard_rank < 0 ||
-        p->shard_rank >= p->shard_count)
+        p->shard_rank >= p->shard_count || (uint64_t)p->sample_begin + p->sample_count > (1ull << 27))
         return fail(ctx, MPT_ERR_INVALID_ARG, "bad render params");
     return MPT_OK;
+}
+
+// Paths one pass may hold.  The global-wavefront queue packs path | bounce << 27 into one word; the wave-local
+// rings and the megakernel carry full 32-bit path ids.  Per-path result slots cost 16 B each: cap a pass at 2^30
+// paths (16 GiB of slots) — a whole 1920x1080x256spp render (531 M paths, 8.5 GB) is ONE pass and ONE launch.
+static inline uint64_t pass_path_limit(int pipeline) {
+    return pipeline == MPT_PIPE_WAVEFRONT ? (1ull << 27) : (1ull << 30);
 }
 
 static inline bool count_flag(const mpt_render_params* p) { return (p->flags & MPT_FLAG_COUNT_WORK) != 0; }
@@ -1262,7 +1338,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
         if (trc) return trc;
     }
     const uint64_t pass_paths = (uint64_t)n_local_tiles * S * 64ull;
-    if (pass_paths >= (1ull << 27)) return fail(ctx, MPT_ERR_INVALID_ARG, "pass too large (internal)");
+    if (pass_paths >= pass_path_limit(p->pipeline)) return fail(ctx, MPT_ERR_INVALID_ARG, "pass too large (internal)");
     uint32_t slots = p->slots_per_iter ? p->slots_per_iter : (16u << 20);
     uint32_t slots_items = std::max<uint32_t>(64, (slots + 63) / 64);
     if ((uint64_t)slots_items * 64 > pass_paths + 64) slots_items = (uint32_t)((pass_paths + 63) / 64);
@@ -1337,16 +1413,16 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
                 hipFree(r.od); hipFree(r.dt); hipFree(r.tl); hipFree(r.ia); hipFree(r.tv);
                 r = WaveRings{};
                 ctx->ring_waves = 0;
-                const size_t n = waves * 2 * MPT_WL_RING;
+                const size_t n = waves * MPT_WL_LEVELS * MPT_WL_RING;
                 HIPCHK(hipMalloc(&r.od, n * 16));
                 HIPCHK(hipMalloc(&r.dt, n * 16));
                 HIPCHK(hipMalloc(&r.tl, n * 16));
                 HIPCHK(hipMalloc(&r.ia, n * 16));
-                HIPCHK(hipMalloc(&r.tv, n * 16));
+                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 24));  // + room for the MPT_DEBUG_WAVE_TIMES records
                 ctx->ring_waves = waves;
             }
-            uint32_t wl_block = ctx->wl_block, budget = ctx->light_budget, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
-            void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&wl_block, (void*)&budget, (void*)&wl_min, (void*)&wl_div};
+            uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
+            void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&ctx->budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
             HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
         } else {
             void* args[] = {(void*)&pp};
@@ -1458,8 +1534,15 @@ extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const uint32_t tiles = ((ctx->W + 7) / 8) * ((ctx->H + 7) / 8);
     const uint32_t local_tiles = (tiles + p->shard_count - 1) / p->shard_count;
-    uint32_t s_max = (uint32_t)std::max<uint64_t>(1, ((1ull << 27) - 64) / ((uint64_t)std::max(1u, local_tiles) * 64ull));
-    if (s_max > 64) s_max = 64;
+    uint32_t s_max = (uint32_t)std::max<uint64_t>(
+        1, (pass_path_limit(p->pipeline) - 64) / ((uint64_t)std::max(1u, local_tiles) * 64ull));
+    if (p->pipeline == MPT_PIPE_WAVEFRONT && s_max > 64) s_max = 64;
+    if (s_max > 0x07FFFFFFu) s_max = 0x07FFFFFFu;
+    {   // keep the samples per pass a power of two when possible (division-free path -> pixel)
+        uint32_t pow2 = 1;
+        while (pow2 * 2 <= s_max) pow2 *= 2;
+        if (p->sample_count >= pow2) s_max = pow2;
+    }
     const char* e = getenv("MPT_PASS_SPP");
     if (e && atoi(e) > 0) s_max = std::min<uint32_t>(s_max, (uint32_t)atoi(e));
     uint32_t done = 0;
@@ -1588,3 +1671,13 @@ extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s
                            (const float*)di[0], (uint32_t)n, (float*)dout[0], (float*)dout[1]);
     });
 }
+
+#ifdef MPT_DEBUG_WAVE_TIMES
+static mpt_ctx* g_dbg_ctx = nullptr;
+extern "C" void mpt_debug_bind(mpt_ctx* ctx) { g_dbg_ctx = ctx; }
+extern "C" int mpt_debug_wave_times(unsigned long long* out, int n) {
+    mpt_ctx* ctx = g_dbg_ctx;
+    const size_t off = ctx->ring_waves * MPT_WL_LEVELS * MPT_WL_RING;
+    return (int)hipMemcpy(out, (const char*)ctx->ring.tv + off * 16, (size_t)n * 24, hipMemcpyDeviceToHost);
+}
+#endif

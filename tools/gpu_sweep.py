@@ -13,7 +13,7 @@ W, H = 1920, 1080
 u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount())
 variants = []
 for spec in os.environ.get("VARIANTS", "MPT_LIGHT_BUDGET=8;MPT_LIGHT_BUDGET=12").split(";"):
-    env = dict(kv.split("=") for kv in spec.split(",") if kv)
+    env = dict(kv.split("=") for kv in spec.split("|") if kv)
     for k, v in env.items(): os.environ[k] = v
     ctx = capi.Context(0); ctx.upload_scene(*bufs); ctx.resize(W, H); ctx.set_uniforms(u)
     for k in env: os.environ.pop(k)

@@ -1,0 +1,29 @@
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from metalpathtracer_amd import capi, host
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", "scene.xml"), sc); assert st == 0
+sc.buildBVH()
+ctx = capi.Context(0); ctx.upload_scene(*sc.buffers())
+W, H = 1920, 1080
+ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
+L = capi.load()
+L.mpt_debug_bind(ctx.h)
+for rep in range(2):
+    ctx.clear_sum(); ctx.reset_stats()
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=64, pipeline=2)
+st = ctx.stats()
+n = 8192
+buf = np.zeros((n, 3), np.uint64)
+L.mpt_debug_wave_times(buf.ctypes.data_as(C.c_void_p), n)
+t0 = buf[:, 0].min()
+start = (buf[:, 0] - t0).astype(np.float64) / 100.0
+exh = (buf[:, 1] - t0).astype(np.float64) / 100.0
+end = (buf[:, 2] - t0).astype(np.float64) / 100.0
+print("kernel ms %.2f" % st["trace_kernel_ms"])
+pc = lambda a: "p1 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(a, [1, 50, 90, 99, 100]))
+print("wave start (us):      ", pc(start))
+print("cursor exhausted (us):", pc(exh))
+print("wave end (us):        ", pc(end))
+print("drain per wave (us):  ", pc(end - exh))
