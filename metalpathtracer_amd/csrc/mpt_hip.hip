@@ -87,6 +87,26 @@ struct PassParams {
     volatile uint32_t* host_done;
 };
 
+// Claim ranges of the single-launch pipelines: range g owns the rank's tiles k with k % MPT_NGROUP == g (every 8th
+// tile along the rows, so all ranges cover the image uniformly, progress at the same rate and run dry together).
+// A range is addressed by a virtual index v in [0, range_paths(g)): v -> tile k = (v / (S*64)) * 8 + g, sample
+// (v / 64) % S, lane v % 64.
+__device__ __forceinline__ uint32_t range_paths(uint32_t n_tiles, uint32_t S, uint32_t g) {
+    const uint32_t n_g = n_tiles > g ? (n_tiles - g + MPT_NGROUP - 1u) / MPT_NGROUP : 0u;
+    return n_g * S * 64u;
+}
+__device__ __forceinline__ uint32_t range_chunk_to_path_chunk(const PassParams& pp, uint32_t vchunk, uint32_t g) {
+    uint32_t tv, s;
+    if (pp.s_shift != 0xFFu) {
+        tv = vchunk >> pp.s_shift;
+        s = vchunk & (pp.S - 1u);
+    } else {
+        tv = vchunk / pp.S;
+        s = vchunk - tv * pp.S;
+    }
+    return (tv * MPT_NGROUP + g) * pp.S + s;  // chunk index in the pass's path-id space: tile * S + sample
+}
+
 // per-wave statistics: reduce over the 64 lanes, one atomic per counter per wave
 template <bool COUNT>
 __device__ __forceinline__ void flush_stats(PassDesc* desc, uint32_t n_rays, uint32_t n_paths, const WorkCount& wc) {
@@ -333,13 +353,19 @@ __device__ void advance_desc(PassDesc* d, uint32_t* ctr, volatile uint32_t* host
 }
 
 __global__ void k_begin_pass(PassDesc* d, uint32_t* ctr, uint32_t total_paths, uint32_t slots_items,
-                             volatile uint32_t* host_done) {
+                             volatile uint32_t* host_done, int path_cursors) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (path_cursors) {  // single-launch pipelines: the cursors count path ids, one contiguous range per group
+        d->total_paths = total_paths;
+        d->overflow = 0;
+        for (uint32_t g = 0; g < MPT_NGROUP; ++g) ctr[MPT_CTR_CURSOR(g)] = 0u;
+        return;
+    }
     for (uint32_t s = 0; s < MPT_NSHARD; ++s) ctr[MPT_CTR_OUT(s)] = 0;
     d->next_path = 0;
     d->total_paths = total_paths;
     d->slots_items = slots_items;
-    d->overflow = 0;
+    d->iterations = 0;  // overflow stays sticky until the host has read it (collect_pass_stats)
     advance_desc(d, ctr, host_done);
 }
 
@@ -425,7 +451,6 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
     const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_paths = pp.desc->total_paths;
-    uint32_t* cursor = &pp.ctr[MPT_CTR_CURSOR(0)];
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wbase = wave_id * (MPT_WL_LEVELS * MPT_WL_RING);
@@ -434,7 +459,10 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
 #pragma unroll
     for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) head[k] = cnt[k] = 0;
     uint32_t cur = 0, end = 0;     // wave-uniform private range of path ids (multiples of 64)
-    uint32_t seen = 0;             // cursor value at this wave's previous claim
+    const uint32_t n_tiles = total_paths / (pp.S * 64u);  // this rank's tiles
+    const uint32_t waves_per_group = (n_waves + MPT_NGROUP - 1u) / MPT_NGROUP;
+    uint32_t grp = blockIdx.x & (MPT_NGROUP - 1u);     // range this wave currently claims from
+    uint32_t seen = 0;                                 // cursor value (virtual index) at this wave's previous claim
     bool exhausted = false;
     uint32_t n_rays = 0, n_paths = 0;
     WorkCount wc = {0, 0, 0, 0, 0, 0};
@@ -450,27 +478,45 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
             if (level < 0 && cnt[k] >= 64u) level = k;
         if (level < 0) {
             if (!exhausted && cur == end) {
-                // guided self-scheduling on the pass cursor: claim remaining / (wl_div * waves) path ids, rounded to whole
-                // 64-path tile samples and clamped to [wl_min, wl_block]: few atomics while there is plenty of work,
-                // fine grain at the end of the pass (tile samples differ ~5x in cost between sky and geometry; with
-                // remaining/(2*waves) the last wave finished 23 ms after the first, with /16 within ~1-2 ms).  `seen` is
-                // the cursor value of this wave's previous claim: an extra load of the hot cursor line before the
-                // atomic made the kernel 4x slower (loads of a line under atomic fire serialise at the memory side).
-                uint32_t k = 0, blk = 0;
+                // Guided self-scheduling of path ids.  The pass's tiles are dealt to MPT_NGROUP interleaved ranges,
+                // each with its own cursor on its own line (a single cursor saturates at ~88 claims/us: in the sky
+                // part of the image a step takes ~1 us and 8192 waves would queue on it).  A wave claims from its
+                // home range (blockIdx % 8: the blocks of one XCD under round-robin placement), then steals from the
+                // next ranges.  Claim size = remaining_in_range / (wl_div * waves_per_range) rounded to whole 64-path
+                // tile samples and clamped to [wl_min, wl_block]: few atomics while there is plenty of work, fine grain
+                // at the end (tile samples differ ~5x in cost between sky and geometry; with remaining/(2*waves) the
+                // last wave finished 23 ms after the first, with /16 within ~1 ms).  `seen` is the cursor value of
+                // this wave's previous claim: an extra load of the hot cursor line before the atomic made the kernel
+                // 4x slower (loads of a line under atomic fire serialise at the memory side).
+                uint32_t k = 0, blk = 0, rend = 0;
+                bool got = false;
                 if (lane == 0) {
-                    const uint32_t left = seen < total_paths ? total_paths - seen : 0u;
-                    blk = (left / (wl_div * n_waves)) & ~63u;
-                    blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
-                    k = atomicAdd(cursor, blk);
+                    for (uint32_t t = 0; t < MPT_NGROUP && !got; ++t) {
+                        const uint32_t re = range_paths(n_tiles, pp.S, grp);
+                        const uint32_t left = seen < re ? re - seen : 0u;
+                        blk = (left / (wl_div * waves_per_group)) & ~63u;
+                        blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
+                        k = atomicAdd(&pp.ctr[MPT_CTR_CURSOR(grp)], blk);
+                        if (k < re) {
+                            got = true;
+                            rend = re;
+                        } else {
+                            grp = (grp + 1u) & (MPT_NGROUP - 1u);
+                            seen = 0;
+                        }
+                    }
                 }
+                got = __builtin_amdgcn_readfirstlane((int)got) != 0;
                 k = __builtin_amdgcn_readfirstlane(k);
                 blk = __builtin_amdgcn_readfirstlane(blk);
+                rend = __builtin_amdgcn_readfirstlane(rend);
+                grp = __builtin_amdgcn_readfirstlane(grp);
                 seen = k;
-                if (k >= total_paths) {
+                if (!got) {
                     exhausted = true;
                 } else {
                     cur = k;
-                    end = (k + blk < total_paths) ? k + blk : total_paths;
+                    end = (k + blk < rend) ? k + blk : rend;
                 }
             }
             if (exhausted) {
@@ -494,7 +540,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
         bool fresh = false;  // this lane starts a new closest-hit query (primary ray or ring-0 record)
         if (level < 0) {
             fresh = true;
-            ps.path = cur + lane;
+            ps.path = range_chunk_to_path_chunk(pp, cur >> 6, grp) * 64u + lane;  // cur is a virtual index of range grp
             cur += 64u;
             uint32_t px, py, sidx;
             if (path_to_pixel(pp, ps.path, px, py, sidx)) {
@@ -748,6 +794,12 @@ struct mpt_ctx {
     std::vector<hipEvent_t> ev_pool;
     // launch geometry
     int wg_size = 1024;
+    const void* occ_fun = nullptr;  // cached occupancy query
+    size_t occ_lds = 0;
+    int occ_per_cu = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_timed;  // single-launch pipelines: events to read later
+    size_t ev_used = 0;
+    PassDesc* h_desc = nullptr;     // pinned copy of the pass descriptor (statistics read-back without a sync copy)
     bool time_kernels = true;
     WaveRings ring = {};       // wave-local wavefront: private light + heavy rings, MPT_WL_RING records each
     size_t ring_waves = 0;
@@ -825,6 +877,7 @@ extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
     if (hipMalloc(&ctx->d_ctr, MPT_CTR_WORDS * 4) != hipSuccess) return bail(MPT_ERR_HIP);
     if (hipMemset(ctx->d_ctr, 0, MPT_CTR_WORDS * 4) != hipSuccess) return bail(MPT_ERR_HIP);
     if (hipHostMalloc((void**)&ctx->h_done, 64, hipHostMallocMapped) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (hipHostMalloc((void**)&ctx->h_desc, sizeof(PassDesc), hipHostMallocDefault) != hipSuccess) return bail(MPT_ERR_HIP);
     *ctx->h_done = 0;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) return bail(MPT_ERR_HIP);
     const char* e;
@@ -895,6 +948,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->ring.tv);
     free_queues(ctx);
     hipHostFree(ctx->h_done);
+    hipHostFree(ctx->h_desc);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
@@ -1391,19 +1445,31 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     const void* kfun = p->pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
                        : p->pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
                                                           : step_kernel(count_flag(p), all_lds);
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfun, ctx->wg_size, lds));
+    if (ctx->occ_fun == kfun && ctx->occ_lds == lds) {
+        per_cu = ctx->occ_per_cu;
+    } else {
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfun, ctx->wg_size, lds));
+        ctx->occ_fun = kfun;
+        ctx->occ_lds = lds;
+        ctx->occ_per_cu = per_cu;
+    }
     if (per_cu < 1) return fail(ctx, MPT_ERR_HIP, "kernel does not fit on a CU");
     if (ctx->wgs_per_cu > 0 && per_cu > ctx->wgs_per_cu) per_cu = ctx->wgs_per_cu;
     const int grid = ctx->prop.multiProcessorCount * per_cu;
     hipStream_t st = ctx->stream;
     *ctx->h_done = 0;
     hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, ctx->d_desc, ctx->d_ctr, (uint32_t)pass_paths, slots_items,
-                       (volatile uint32_t*)dev_done);
+                       (volatile uint32_t*)dev_done, p->pipeline == MPT_PIPE_WAVEFRONT ? 0 : 1);
     if (p->pipeline == MPT_PIPE_MEGAKERNEL || p->pipeline == MPT_PIPE_WAVELOCAL) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (time_kernels) {
-            HIPCHK(hipEventCreate(&e0));
-            HIPCHK(hipEventCreate(&e1));
+        if (time_kernels) {  // events from the context's pool; they are read after the ONE sync of mpt_render / mpt_draw
+            while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                ctx->ev_pool.push_back(e);
+            }
+            e0 = ctx->ev_pool[ctx->ev_used++];
+            e1 = ctx->ev_pool[ctx->ev_used++];
             HIPCHK(hipEventRecord(e0, st));
         }
         if (p->pipeline == MPT_PIPE_WAVELOCAL) {
@@ -1430,20 +1496,14 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
         }
         if (time_kernels) {
             HIPCHK(hipEventRecord(e1, st));
-            HIPCHK(hipEventSynchronize(e1));
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-            ctx->stats.trace_kernel_ms += ms;
-            ctx->stats.trace_launches += 1;
-            hipEventDestroy(e0);
-            hipEventDestroy(e1);
+            ctx->pending_timed.emplace_back(e0, e1);
         }
         ctx->stats.iterations += 1;
         return MPT_OK;
     }
     // wavefront: enqueue iterations in batches; the device publishes `done` to pinned host memory
     std::vector<hipEvent_t>& pool = ctx->ev_pool;
-    size_t ev_used = 0;
+    size_t& ev_used = ctx->ev_used;
     auto get_event = [&]() -> hipEvent_t {
         if (ev_used == pool.size()) {
             hipEvent_t e;
@@ -1491,25 +1551,39 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
         if (launched > hard_cap) return fail(ctx, MPT_ERR_HIP, "pass did not drain (internal)");
         batch = 4;
     }
-    if (time_kernels) {
+    {
         PassDesc hd;
         HIPCHK(hipMemcpy(&hd, ctx->d_desc, sizeof hd, hipMemcpyDeviceToHost));
         // only the iterations that had work count as launches of the dominant kernel
-        uint64_t real = hd.iterations;
+        const uint64_t real = hd.iterations;
         for (size_t i = 0; i < timed.size() && i < real; ++i) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, timed[i].first, timed[i].second));
             ctx->stats.trace_kernel_ms += ms;
             if (getenv("MPT_DEBUG_ITERS")) fprintf(stderr, "[mpt] iter %zu: %.3f ms\n", i, ms);
         }
-        ctx->stats.trace_launches += real;
+        if (time_kernels) ctx->stats.trace_launches += real;
+        ctx->stats.iterations += real;
     }
     return MPT_OK;
 }
 
+// Statistics of everything enqueued since the last collection: one asynchronous copy of the pass descriptor into
+// pinned memory, ONE host synchronisation, then the kernel-event pairs recorded meanwhile are read.
 static int collect_pass_stats(mpt_ctx* ctx) {
-    PassDesc hd;
-    HIPCHK(hipMemcpy(&hd, ctx->d_desc, sizeof hd, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(ctx->h_desc, ctx->d_desc, sizeof(PassDesc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemsetAsync(&ctx->d_desc->paths, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(&ctx->d_desc->overflow, 0, 4, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const PassDesc& hd = *ctx->h_desc;
+    for (auto& pr : ctx->pending_timed) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->stats.trace_kernel_ms += ms;
+        ctx->stats.trace_launches += 1;
+    }
+    ctx->pending_timed.clear();
+    ctx->ev_used = 0;
     if (hd.overflow) return fail(ctx, MPT_ERR_OVERFLOW, "ray ring overflow");
     ctx->stats.paths += hd.paths;
     ctx->stats.rays += hd.rays;
@@ -1519,9 +1593,6 @@ static int collect_pass_stats(mpt_ctx* ctx) {
     ctx->stats.wave_node_iters += hd.node_iters;
     ctx->stats.wave_prim_iters += hd.prim_iters;
     ctx->stats.wave_leaf_phases += hd.leaf_phases;
-    ctx->stats.iterations += hd.iterations;
-    HIPCHK(hipMemsetAsync(&ctx->d_desc->paths, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    HIPCHK(hipMemsetAsync(&ctx->d_desc->iterations, 0, 4, ctx->stream));
     return MPT_OK;
 }
 
@@ -1557,12 +1628,11 @@ extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
             hipLaunchKernelGGL(k_resolve_sum, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, pp, ctx->d_sum, nlt);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if ((rc = collect_pass_stats(ctx))) return rc;
         done += S;
+        // the next pass reuses the slot buffer and the descriptor: in-stream order is enough, no host sync here
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipEventSynchronize(ctx->ev1));
+    if ((rc = collect_pass_stats(ctx))) return rc;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->stats.total_ms = ms;

@@ -12,7 +12,7 @@ L = capi.load()
 L.mpt_debug_bind(ctx.h)
 for rep in range(2):
     ctx.clear_sum(); ctx.reset_stats()
-    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=64, pipeline=2)
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2)
 st = ctx.stats()
 n = 8192
 buf = np.zeros((n, 3), np.uint64)
