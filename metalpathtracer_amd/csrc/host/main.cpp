@@ -19,6 +19,7 @@ static void usage() {
         "mpt_render --scene scene.xml [--asset-root DIR] [--width 1280] [--height 720]\n"
         "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter]\n"
         "           [--pipeline wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
+        "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
         "  --frames N   run the reference's frame protocol (N draw() calls, running mean) instead of batch spp");
 }
 
@@ -26,6 +27,8 @@ int main(int argc, char** argv) {
     std::string scene, assetRoot, out;
     int width = 1280, height = 720, spp = 64, depth = 32, device = 0, frames = 0;
     unsigned seed = 1;
+    float camPos[3], camDir[3], camUp[3], vfov = 0.0f;
+    bool havePos = false, haveDir = false, haveUp = false;
     mpt_render_params prm;
     std::memset(&prm, 0, sizeof prm);
     prm.rng_mode = MPT_RNG_PHILOX;
@@ -50,6 +53,17 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--frames") frames = std::atoi(next());
         else if (a == "--out") out = next();
+        else if (a == "--camera-pos" || a == "--camera-dir" || a == "--camera-up") {
+            float v[3] = {0, 0, 0};
+            if (std::sscanf(next(), "%f,%f,%f", &v[0], &v[1], &v[2]) != 3) {
+                usage();
+                return 2;
+            }
+            float* dst = a == "--camera-pos" ? camPos : (a == "--camera-dir" ? camDir : camUp);
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+            (a == "--camera-pos" ? havePos : (a == "--camera-dir" ? haveDir : haveUp)) = true;
+        }
+        else if (a == "--vfov") vfov = static_cast<float>(std::atof(next()));
         else if (a == "--rng") prm.rng_mode = std::strcmp(next(), "literal") == 0 ? MPT_RNG_LITERAL : MPT_RNG_PHILOX;
         else if (a == "--bsdf") prm.bsdf_mode = std::strcmp(next(), "scatter") == 0 ? MPT_BSDF_SCATTER : MPT_BSDF_LAMBERT;
         else if (a == "--pipeline") {
@@ -71,6 +85,11 @@ int main(int argc, char** argv) {
     try {
         Renderer r(device, scene, assetRoot);
         r.setRenderParams(prm);
+        // the reference hard-codes Camera::reset(); the flags overwrite the same globals before the viewport is built
+        if (havePos) Camera::position = mpt::float3(camPos[0], camPos[1], camPos[2]);
+        if (haveDir) Camera::forward = mpt::normalize(mpt::float3(camDir[0], camDir[1], camDir[2]));
+        if (haveUp) Camera::up = mpt::normalize(mpt::float3(camUp[0], camUp[1], camUp[2]));
+        if (vfov > 0.0f) Camera::verticalFov = vfov;
         OffscreenView view;
         r.drawableSizeWillChange(&view, DrawableSize{(double)width, (double)height});
         std::vector<float> img;
