@@ -121,8 +121,10 @@ def test_small_wavefront_width_and_sample_ranges(gpu_ctx):
     gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=6, seed=(3, 9))
     whole = gpu_ctx.read_sum()
     gpu_ctx.clear_sum()
-    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_begin=0, sample_count=2, seed=(3, 9), slots_per_iter=512)
-    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_begin=2, sample_count=4, seed=(3, 9), slots_per_iter=4096)
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_begin=0, sample_count=2, seed=(3, 9), slots_per_iter=512,
+                   pipeline=capi.PIPE_WAVEFRONT)
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_begin=2, sample_count=4, seed=(3, 9), slots_per_iter=4096,
+                   pipeline=capi.PIPE_WAVEFRONT)
     parts = gpu_ctx.read_sum()
     np.testing.assert_array_equal(whole.view(np.uint32), parts.view(np.uint32))
     ref, _ = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, max_depth=8, accumulate=1, sample_count=6, seed=(3, 9), threads=8)
