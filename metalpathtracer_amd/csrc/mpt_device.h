@@ -93,6 +93,11 @@ __device__ __forceinline__ void sincos_2pi(float u, float& s_out, float& c_out) 
     c_out = (k == 0) ? c : (k == 1) ? -s : (k == 2) ? -c : s;
 }
 
+// LDS image: an explicit address-space-3 pointer so that fetches are ds_read_b128, never flat loads
+// (a generic pointer selected between LDS and global turns into flat_load: measured 0 LDS reads per ray).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) v4f* LdsNodes;
+
 // ---- scene on the device ----------------------------------------------------------------------------
 // Threaded BVH node, 32 bytes (same size as the reference's, SURVEY App. D buf 0):
 //   n0 = (bmin.xyz, A)   n1 = (bmax.xyz, B)
@@ -110,6 +115,7 @@ struct SceneDev {
     const float4* mats;   // 2 float4 per unique material: (albedo, type) (emission, power)
     uint32_t n_nodes;
     uint32_t n_lds_nodes;  // nodes [0, n_lds_nodes) are also in LDS
+    uint32_t n_lds_prims;  // primitives [0, n_lds_prims) are also in LDS, right behind the node image
     uint32_t n_prims;
     uint32_t n_mats;
 };
@@ -135,16 +141,37 @@ struct WorkCount {
     uint32_t node_iters, prim_iters, outer_iters;  // per WAVE loop trips (lane 0 only): x64 = issued lane slots
 };
 
+// One primitive record (3 x 16 B).  Primitives are stored by leaf depth (shallow leaves first); the first
+// n_lds_prims of them are staged in LDS behind the node image.  On scene.xml 65 % of all primitive tests hit the three
+// spheres near the root: from LDS they cost three ds_read_b128 instead of three scattered L2 requests per lane.
+struct Prim3 {
+    float4 p0, p1, p2;
+};
+__device__ __forceinline__ Prim3 load_prim(const SceneDev& sc, LdsNodes lds, uint32_t i) {
+    Prim3 r;
+    if (i < sc.n_lds_prims) {
+        const LdsNodes q = lds + 2u * sc.n_lds_nodes + 3u * i;
+        const v4f a = q[0], b = q[1], c = q[2];
+        r.p0 = make_float4(a.x, a.y, a.z, a.w);
+        r.p1 = make_float4(b.x, b.y, b.z, b.w);
+        r.p2 = make_float4(c.x, c.y, c.z, c.w);
+    } else {
+        r.p0 = sc.prims[3 * i];
+        r.p1 = sc.prims[3 * i + 1];
+        r.p2 = sc.prims[3 * i + 2];
+    }
+    return r;
+}
+
 // Primitives of one leaf, in index order — PathTracing.h:106-186.
 template <bool COUNT>
-__device__ __forceinline__ void leaf_test(const SceneDev& sc, uint32_t first, uint32_t count, F3 o, F3 d,
+__device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint32_t first, uint32_t count, F3 o, F3 d,
                                           float& best_t, int& best_prim, WorkCount& wc) {
     for (uint32_t k = 0; k < count; ++k) {
         // the three 16-byte loads of a primitive are issued together (the third is used by triangles only, but a
         // load that waits for the type check costs a second L2 round trip per primitive)
-        const float4 p0 = sc.prims[3 * (first + k)];
-        const float4 p1 = sc.prims[3 * (first + k) + 1];
-        const float4 p2 = sc.prims[3 * (first + k) + 2];
+        const Prim3 pr = load_prim(sc, lds, first + k);
+        const float4 p0 = pr.p0, p1 = pr.p1, p2 = pr.p2;
         if (COUNT) {
             wc.prim_tests++;
             if (first_active_lane()) wc.prim_iters++;
@@ -194,8 +221,6 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, uint32_t first, ui
 // order (right child first, leaf primitives in index order), so ties resolve identically.
 // LDS node image: an explicit address-space-3 pointer so that node fetches are ds_read_b128, never flat loads
 // (a generic pointer selected between LDS and global turns into flat_load: measured 0 LDS reads per ray).
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(3))) v4f* LdsNodes;
 
 // Resumable closest hit with a wave-level budget of box-test loop trips.
 //   in/out: node (next node to visit, 0 = root), best_t, best_prim  (fresh query: 0, +inf, -1)
@@ -259,7 +284,7 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
         if (BUDGETED) trips = wave_max_u32(trips);
         if (leaf_count != 0u) {
             if (COUNT && first_active_lane()) wc.outer_iters++;
-            leaf_test<COUNT>(sc, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
+            leaf_test<COUNT>(sc, lds_nodes, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
         }
         // the wave goes round again only while some lane still has nodes to visit and budget is left
         if (__ballot(i < n_nodes && (!BUDGETED || trips < budget)) == 0ull) break;
@@ -285,9 +310,10 @@ struct HitInfo {
 };
 // Surface point / geometric normal of the winning primitive — the values PathTracing.h:138-139,
 // 168-169 compute when the hit is accepted, and the front-face flip of :196-201.
-__device__ __forceinline__ HitInfo finish_hit(const SceneDev& sc, F3 o, F3 d, float t, int prim) {
+__device__ __forceinline__ HitInfo finish_hit(const SceneDev& sc, LdsNodes lds, F3 o, F3 d, float t, int prim) {
     HitInfo h;
-    const float4 p0 = sc.prims[3 * prim], p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
+    const Prim3 pr = load_prim(sc, lds, (uint32_t)prim);
+    const float4 p0 = pr.p0, p1 = pr.p1, p2 = pr.p2;
     h.point = o + t * d;
     if ((int)p0.w == 1) {
         h.normal = normalize3(cross3(f3(p1.x, p1.y, p1.z), f3(p2.x, p2.y, p2.z)));
@@ -365,7 +391,7 @@ __device__ __forceinline__ bool mirror_angle(float ri, F3 normal, F3 rayDir, flo
 // One iteration of the bounce loop of rayColor (PathTracing.h:221-256) for a ray whose closest hit is
 // (t, prim).  Returns true if the path continues (ps holds the next ray), false if it ended (ps.L/La
 // hold the final light, to be clamped by the caller: PathTracing.h:258).
-__device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const ShadeParams& sp, const PathRngDev& g,
+__device__ __forceinline__ bool shade_bounce(const SceneDev& sc, LdsNodes lds, const ShadeParams& sp, const PathRngDev& g,
                                              PathState& ps, float t, int prim) {
     if (prim < 0) {  // PathTracing.h:225-232 sky
         F3 ud = normalize3(ps.d);
@@ -377,7 +403,7 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const ShadePara
         ps.La += 1.0f;
         return false;
     }
-    HitInfo h = finish_hit(sc, ps.o, ps.d, t, prim);
+    HitInfo h = finish_hit(sc, lds, ps.o, ps.d, t, prim);
     if ((uint32_t)h.orig_id >= sp.primitive_count) return false;  // PathTracing.h:234-236
     const float4 m0 = sc.mats[2 * h.mat], m1 = sc.mats[2 * h.mat + 1];
     const float mtype = m0.w, power = m1.w;

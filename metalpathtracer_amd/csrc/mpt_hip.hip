@@ -190,8 +190,9 @@ __device__ __forceinline__ void rng_for_path(const PassParams& pp, uint32_t path
 }
 
 __device__ __forceinline__ void stage_nodes(const SceneDev& sc, float4* lds) {
-    const uint32_t n4 = sc.n_lds_nodes * 2u;
+    const uint32_t n4 = sc.n_lds_nodes * 2u, p4 = sc.n_lds_prims * 3u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < p4; i += blockDim.x) lds[n4 + i] = sc.prims[i];
     __syncthreads();
 }
 
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uin
     extern __shared__ float4 lds_nodes[];
     PassDesc* desc = pp.desc;
     if (desc->n_items == 0) return;  // drained: iterations enqueued past the end of the pass cost a launch only
-    // iteration descriptor -> LDS, behind the node image (16-byte aligned: n_lds_nodes * 32 bytes)
-    uint32_t* s_prefix = (uint32_t*)(lds_nodes + 2 * pp.scene.n_lds_nodes);  // [NSHARD+1]
+    // iteration descriptor -> LDS, behind the node + primitive image (16-byte aligned)
+    uint32_t* s_prefix = (uint32_t*)(lds_nodes + 2 * pp.scene.n_lds_nodes + 3 * pp.scene.n_lds_prims);  // [NSHARD+1]
     uint32_t* s_incount = s_prefix + (MPT_NSHARD + 1);                        // [NSHARD]
     uint32_t* s_range_end = s_incount + MPT_NSHARD;                          // [NGROUP]
     if (threadIdx.x <= MPT_NSHARD) s_prefix[threadIdx.x] = desc->item_prefix[threadIdx.x];
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uin
             int prim;
             closest_hit<COUNT, ALL_LDS>(pp.scene, (LdsNodes)lds_nodes, ps.o, ps.d, t, prim, wc);
             n_rays++;
-            alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
+            alive = shade_bounce(pp.scene, (LdsNodes)lds_nodes, pp.sp, g, ps, t, prim);
             if (!alive)  // PathTracing.h:258 per-sample clamp
                 pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
         }
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams p
             int prim;
             closest_hit<COUNT, ALL_LDS>(pp.scene, (LdsNodes)lds_nodes, ps.o, ps.d, t, prim, wc);
             n_rays++;
-            alive = shade_bounce(pp.scene, pp.sp, g, ps, t, prim);
+            alive = shade_bounce(pp.scene, (LdsNodes)lds_nodes, pp.sp, g, ps, t, prim);
         }
         pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
     }
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                                                                 0xFFFFFFFFu, wc);
             if (fresh) n_rays++;  // a resumed query was counted when it started
             if (done) {
-                alive = shade_bounce(pp.scene, pp.sp, g, ps, best_t, best_prim);
+                alive = shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, best_prim);
                 if (!alive)
                     pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
             } else {
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_trace_rays(SceneDev sc, const float* o
     closest_hit<false, false>(sc, (LdsNodes)lds_nodes, ro, rd, t, prim, wc);
     t_out[i] = t;
     if (prim >= 0) {
-        HitInfo h = finish_hit(sc, ro, rd, t, prim);
+        HitInfo h = finish_hit(sc, (LdsNodes)lds_nodes, ro, rd, t, prim);
         prim_out[i] = h.orig_id;
         n_out[3 * i] = h.normal.x;
         n_out[3 * i + 1] = h.normal.y;
@@ -763,7 +764,7 @@ struct mpt_ctx {
     float4* d_nodes = nullptr;
     float4* d_prims = nullptr;
     float4* d_mats = nullptr;
-    uint32_t n_nodes = 0, n_prims = 0, n_mats = 0, n_lds_nodes = 0;
+    uint32_t n_nodes = 0, n_prims = 0, n_mats = 0, n_lds_nodes = 0, n_lds_prims = 0;
     bool have_scene = false;
     // uniforms / size
     mpt_uniforms u;
@@ -808,7 +809,7 @@ struct mpt_ctx {
     uint32_t wl_min = 64, wl_div = 16;  // guided path-id claims: max(wl_min, remaining / (wl_div * waves))
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
-    size_t lds_budget = 60 * 1024;
+    size_t lds_budget = 78 * 1024;  // per workgroup; two workgroups per CU share the 160 KiB
     mpt_stats stats = {};
 };
 
@@ -1139,6 +1140,20 @@ extern "C" int mpt_upload_scene(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes
     std::vector<uint32_t> inv(ND + 1);
     for (uint32_t i = 0; i < ND; ++i) inv[perm[i]] = i;
     inv[ND] = ND;  // terminator
+    // primitives follow the same breadth-first order as the nodes: the leaves next to the root come first, so a
+    // prefix of the primitive array (the part staged in LDS) holds the most frequently tested primitives
+    {
+        std::vector<float> ordered(dprims.size());
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < ND; ++i) {
+            DNode& d = dn[perm[i]];
+            if (!d.leaf) continue;
+            memcpy(ordered.data() + (size_t)at * 12, dprims.data() + (size_t)d.first * 12, (size_t)d.count * 48);
+            d.first = at;
+            at += d.count;
+        }
+        dprims.swap(ordered);
+    }
     std::vector<float> dnodes((size_t)ND * 8);
     for (uint32_t i = 0; i < ND; ++i) {
         const DNode& d = dn[perm[i]];
@@ -1168,7 +1183,18 @@ extern "C" int mpt_upload_scene(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes
     ctx->n_nodes = ND;
     ctx->n_prims = (uint32_t)(dprims.size() / 12);
     ctx->n_mats = (uint32_t)(mat_table.size() / 8);
-    ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ND, ctx->lds_budget / 32);
+    // LDS image = top of the tree + primitives of the shallowest leaves.  When the whole tree fits, the rest of the
+    // budget goes to primitives; otherwise 6 KiB are reserved for them (the leaves next to the root are visited by
+    // almost every ray: on scene.xml the three spheres take 65 % of all primitive tests).
+    {
+        const size_t budget = ctx->lds_budget > MPT_LDS_EXTRA ? ctx->lds_budget - MPT_LDS_EXTRA : 0;
+        const size_t all_nodes = (size_t)ND * 32, all_prims = dprims.size() / 12 * 48;
+        size_t prim_bytes = all_nodes <= budget ? std::min(all_prims, budget - all_nodes)
+                                                : std::min<size_t>(all_prims, std::min<size_t>(6 * 1024, budget / 4));
+        prim_bytes -= prim_bytes % 48;
+        ctx->n_lds_prims = (uint32_t)(prim_bytes / 48);
+        ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ND, (budget - prim_bytes) / 32);
+    }
     ctx->have_scene = true;
     return MPT_OK;
 }
@@ -1266,6 +1292,7 @@ static SceneDev scene_dev(const mpt_ctx* ctx) {
     s.mats = ctx->d_mats;
     s.n_nodes = ctx->n_nodes;
     s.n_lds_nodes = ctx->n_lds_nodes;
+    s.n_lds_prims = ctx->n_lds_prims;
     s.n_prims = ctx->n_prims;
     s.n_mats = ctx->n_mats;
     return s;
@@ -1439,7 +1466,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     // test mode: poison the per-path result slots so that a path that is lost shows up as NaN in the image
     if (count_flag(p)) HIPCHK(hipMemsetAsync(ctx->d_slots, 0xFF, pass_paths * 16, ctx->stream));
 
-    const size_t lds = (size_t)ctx->n_lds_nodes * 32 + MPT_LDS_EXTRA;
+    const size_t lds = (size_t)ctx->n_lds_nodes * 32 + (size_t)ctx->n_lds_prims * 48 + MPT_LDS_EXTRA;
     int per_cu = 0;
     const bool all_lds = ctx->n_lds_nodes == ctx->n_nodes;
     const void* kfun = p->pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
@@ -1677,7 +1704,7 @@ extern "C" int mpt_trace_rays(mpt_ctx* ctx, const float* o, const float* d, uint
     HIPCHK(hipMemcpy(d_o, o, n * 12, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_d, d, n * 12, hipMemcpyHostToDevice));
     SceneDev sc = scene_dev(ctx);
-    hipLaunchKernelGGL(k_trace_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), (size_t)ctx->n_lds_nodes * 32 + MPT_LDS_EXTRA,
+    hipLaunchKernelGGL(k_trace_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), (size_t)ctx->n_lds_nodes * 32 + (size_t)ctx->n_lds_prims * 48 + MPT_LDS_EXTRA,
                        ctx->stream, sc, (const float*)d_o, (const float*)d_d, (uint32_t)n, d_t, d_p, d_n, d_f);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
