@@ -224,8 +224,8 @@ def main():
                 "rays_per_launch": rays_per_launch,
                 "algorithmic_bytes_per_launch": b_ray * rays_per_launch,
                 "note": "achieved = SURVEY 8(d) algorithmic bytes/ray x rays per launch / avg launch time; frac > 1 "
-                        "means the kernel is not HBM-bound: the scene (0.5 MB) is served from LDS/L2, measured HBM-side "
-                        "traffic is ~158 B/ray (traffic field, bytes per launch)",
+                        "means the kernel is not HBM-bound: the scene (0.5 MB) is served from LDS/L2; `traffic` = measured "
+                        "L2<->fabric bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)",
             }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -116,6 +116,7 @@ struct SceneDev {
     uint32_t n_nodes;
     uint32_t n_lds_nodes;  // nodes [0, n_lds_nodes) are also in LDS
     uint32_t n_lds_prims;  // primitives [0, n_lds_prims) are also in LDS, right behind the node image
+    uint32_t n_lds_mats;   // materials [0, n_lds_mats) are also in LDS, behind the primitives
     uint32_t n_prims;
     uint32_t n_mats;
 };
@@ -405,7 +406,16 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, LdsNodes lds, c
     }
     HitInfo h = finish_hit(sc, lds, ps.o, ps.d, t, prim);
     if ((uint32_t)h.orig_id >= sp.primitive_count) return false;  // PathTracing.h:234-236
-    const float4 m0 = sc.mats[2 * h.mat], m1 = sc.mats[2 * h.mat + 1];
+    float4 m0, m1;
+    if ((uint32_t)h.mat < sc.n_lds_mats) {  // the de-duplicated material table is tiny: served from LDS
+        const LdsNodes q = lds + 2u * sc.n_lds_nodes + 3u * sc.n_lds_prims + 2u * (uint32_t)h.mat;
+        const v4f a = q[0], b = q[1];
+        m0 = make_float4(a.x, a.y, a.z, a.w);
+        m1 = make_float4(b.x, b.y, b.z, b.w);
+    } else {
+        m0 = sc.mats[2 * h.mat];
+        m1 = sc.mats[2 * h.mat + 1];
+    }
     const float mtype = m0.w, power = m1.w;
     if (power > 0.0f || mtype == 2.0f) {  // PathTracing.h:245-249
         ps.L.x += ps.thr.x * m1.x * power;

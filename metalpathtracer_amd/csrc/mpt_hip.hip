@@ -193,6 +193,7 @@ __device__ __forceinline__ void stage_nodes(const SceneDev& sc, float4* lds) {
     const uint32_t n4 = sc.n_lds_nodes * 2u, p4 = sc.n_lds_prims * 3u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = sc.nodes[i];
     for (uint32_t i = threadIdx.x; i < p4; i += blockDim.x) lds[n4 + i] = sc.prims[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_lds_mats * 2u; i += blockDim.x) lds[n4 + p4 + i] = sc.mats[i];
     __syncthreads();
 }
 
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uin
     PassDesc* desc = pp.desc;
     if (desc->n_items == 0) return;  // drained: iterations enqueued past the end of the pass cost a launch only
     // iteration descriptor -> LDS, behind the node + primitive image (16-byte aligned)
-    uint32_t* s_prefix = (uint32_t*)(lds_nodes + 2 * pp.scene.n_lds_nodes + 3 * pp.scene.n_lds_prims);  // [NSHARD+1]
+    uint32_t* s_prefix = (uint32_t*)(lds_nodes + 2 * pp.scene.n_lds_nodes + 3 * pp.scene.n_lds_prims + 2 * pp.scene.n_lds_mats);  // [NSHARD+1]
     uint32_t* s_incount = s_prefix + (MPT_NSHARD + 1);                        // [NSHARD]
     uint32_t* s_range_end = s_incount + MPT_NSHARD;                          // [NGROUP]
     if (threadIdx.x <= MPT_NSHARD) s_prefix[threadIdx.x] = desc->item_prefix[threadIdx.x];
@@ -828,7 +829,8 @@ static const void* wavelocal_kernel(bool count, bool all_lds) {
     return all_lds ? (const void*)k_wavelocal<false, true> : (const void*)k_wavelocal<false, false>;
 }
 
-#define MPT_LDS_EXTRA 256  // iteration descriptor copy behind the node image
+#define MPT_LDS_MATS 32u                        // materials staged in LDS (32 B each)
+#define MPT_LDS_EXTRA (256 + MPT_LDS_MATS * 32)  // descriptor copy + material table behind the scene image
 
 #define HIPCHK(call)                                                                        \
     do {                                                                                    \
@@ -1293,6 +1295,7 @@ static SceneDev scene_dev(const mpt_ctx* ctx) {
     s.n_nodes = ctx->n_nodes;
     s.n_lds_nodes = ctx->n_lds_nodes;
     s.n_lds_prims = ctx->n_lds_prims;
+    s.n_lds_mats = std::min<uint32_t>(ctx->n_mats, MPT_LDS_MATS);
     s.n_prims = ctx->n_prims;
     s.n_mats = ctx->n_mats;
     return s;
