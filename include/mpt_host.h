@@ -58,6 +58,9 @@ int mpt_renderer_destroy(mpt_renderer* r);
 int mpt_renderer_drawable_size_will_change(mpt_renderer* r, uint32_t width, uint32_t height);
 int mpt_renderer_set_params(mpt_renderer* r, const mpt_render_params* p);
 int mpt_renderer_draw(mpt_renderer* r);                       /* updateUniforms + one frame              */
+/* InputSystem state consumed by the next draw (R/Window/InputSystem.h:11-21, R/Renderer/Camera.h:75-89): any
+ * non-zero input moves the camera, which resets frameCount and draws a new randomSeed (Renderer.cpp:255-257)   */
+int mpt_renderer_input(mpt_renderer* r, const float move[3], const float rotate[2], float zoom, int reset);
 int mpt_renderer_read_frame(mpt_renderer* r, float* rgba);    /* W*H*4 floats                            */
 int mpt_renderer_render_batch(mpt_renderer* r, uint32_t sample_begin, uint32_t sample_count);
 int mpt_renderer_read_sum(mpt_renderer* r, float* rgba);

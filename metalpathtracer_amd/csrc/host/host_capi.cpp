@@ -194,6 +194,14 @@ int mpt_renderer_draw(mpt_renderer* r) {
     if (!r) return MPT_ERR_INVALID_ARG;
     GUARD(r->r->draw(nullptr));
 }
+int mpt_renderer_input(mpt_renderer* r, const float move[3], const float rotate[2], float zoom, int reset) {
+    if (!r) return MPT_ERR_INVALID_ARG;
+    if (move) InputSystem::movementInput = mpt::float3(move[0], move[1], move[2]);
+    if (rotate) InputSystem::rotationInput = mpt::float2{rotate[0], rotate[1]};
+    InputSystem::zoomInput = zoom;
+    InputSystem::resetInput = reset != 0;
+    return MPT_OK;
+}
 int mpt_renderer_read_frame(mpt_renderer* r, float* rgba) {
     if (!r || !rgba) return MPT_ERR_INVALID_ARG;
     return mpt_read_frame(r->r->context(), rgba);

@@ -20,7 +20,7 @@ SYMBOLS = (
     "mpt_scene_create", "mpt_scene_destroy", "mpt_scene_clear", "mpt_scene_load_xml", "mpt_scene_add_primitive",
     "mpt_scene_build_bvh", "mpt_scene_counts", "mpt_scene_copy_buffers", "mpt_camera_reset_values",
     "mpt_camera_viewport", "mpt_host_random_float", "mpt_renderer_create", "mpt_renderer_destroy",
-    "mpt_renderer_drawable_size_will_change", "mpt_renderer_set_params", "mpt_renderer_draw",
+    "mpt_renderer_drawable_size_will_change", "mpt_renderer_set_params", "mpt_renderer_draw", "mpt_renderer_input",
     "mpt_renderer_read_frame", "mpt_renderer_render_batch", "mpt_renderer_read_sum", "mpt_renderer_clear_sum",
     "mpt_renderer_uniforms", "mpt_renderer_stats", "mpt_renderer_context", "mpt_renderer_scene", "mpt_write_pfm",
     "mpt_write_ppm",
@@ -56,6 +56,7 @@ def load():
     L.mpt_renderer_drawable_size_will_change.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.mpt_renderer_set_params.argtypes = [vp, C.POINTER(capi.RenderParams)]
     L.mpt_renderer_draw.argtypes = [vp]
+    L.mpt_renderer_input.argtypes = [vp, fp, fp, C.c_float, C.c_int]
     L.mpt_renderer_read_frame.argtypes = [vp, fp]
     L.mpt_renderer_render_batch.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.mpt_renderer_read_sum.argtypes = [vp, fp]
@@ -232,6 +233,11 @@ class Renderer:
 
     def draw(self):
         self._chk(self.L.mpt_renderer_draw(self.h), "draw")
+
+    def input(self, move=(0, 0, 0), rotate=(0, 0), zoom=0.0, reset=False):
+        """InputSystem state for the next draw (movementInput, rotationInput, zoomInput, resetInput)."""
+        self._chk(self.L.mpt_renderer_input(self.h, _f3(move), (C.c_float * 2)(*[float(x) for x in rotate]), float(zoom),
+                                            int(bool(reset))), "input")
 
     def readFrame(self):
         out = np.empty((self.height, self.width, 4), np.float32)

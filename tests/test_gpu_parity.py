@@ -446,3 +446,34 @@ def test_cli_mpt_render_matches_golden(tmp_path):
     img = np.frombuffer(raw[len(hdr):], np.float32).reshape(64, 64, 3)[::-1]
     want = np.load(os.path.join(GOLDEN, "cornell_philox_16spp.npy"))
     np.testing.assert_array_equal(img, want[..., :3] * np.float32(1.0 / 16))
+
+
+def test_camera_move_resets_accumulation_and_reseeds(gpu_ctx):
+    """Renderer::updateUniforms (R/Renderer/Renderer.cpp:251-267): a camera change sets frameCount = 0 and draws
+    randomSeed from the host PCG stream (first triple = SURVEY App. C.1); the next still frame counts up again.
+    The frame rendered after the move matches the oracle with those uniforms (literal RNG, sin-hash pixel seeds)."""
+    from metalpathtracer_amd import host
+    r = host.Renderer(0, scene_path("scene.xml"))
+    r.drawableSizeWillChange(128, 72)
+    r.draw()
+    assert r.uniforms().frameCount == 1
+    r.input(move=(0, 0, 1))                      # one step forward (movementSpeed 0.1, Camera.h:20,35-47)
+    r.draw()
+    u = r.uniforms()
+    assert u.frameCount == 0
+    assert list(u.randomSeed)[:3] == pytest.approx([0.80921644, 0.38028690, 0.09423842], abs=5e-9)
+    assert list(u.cameraPosition)[:3] == pytest.approx([0.0, 20.0, 49.9], abs=1e-5)
+    got = r.readFrame()
+    sc, buf = oracle_scene("scene.xml")
+    ref, _ = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG_LITERAL, max_depth=32, accumulate=0,
+                       last=np.ones((72, 128, 4), np.float32), threads=8)   # frameCount 0: lastFrame is cleared
+    # device sinf/cosf differ from glibc in the last ulp of the (stuck) bounce vector: a silhouette pixel may flip
+    assert pixel_l2(got, ref) < L2_TOL and (np.abs(got - ref).max(-1) > 1e-3).sum() <= 3
+    r.draw()
+    assert r.uniforms().frameCount == 1 and list(r.uniforms().randomSeed)[:3] == list(u.randomSeed)[:3]
+    r.input(reset=True)
+    r.draw()
+    u2 = r.uniforms()
+    assert u2.frameCount == 0 and list(u2.cameraPosition)[:3] == [0.0, 20.0, 50.0]
+    assert list(u2.randomSeed)[:3] != list(u.randomSeed)[:3]
+    r.close()
