@@ -12,7 +12,7 @@ HOSTFLAGS ?= -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wal
 
 all: $(LIBDIR)/libmpt_hip.so host oracle
 
-$(LIBDIR)/libmpt_hip.so: $(PKG)/csrc/mpt_hip.hip $(PKG)/csrc/mpt_device.h include/mpt.h
+$(LIBDIR)/libmpt_hip.so: $(PKG)/csrc/mpt_hip.hip $(PKG)/csrc/mpt_kernels.h $(PKG)/csrc/mpt_device.h include/mpt.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
 

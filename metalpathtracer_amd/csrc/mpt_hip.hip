@@ -1,18 +1,10 @@
-// mpt_hip.hip — kernels and C ABI (include/mpt.h) of the MI355X path-tracing hot path.
+// mpt_hip.hip — host side of the C ABI (include/mpt.h) of the MI355X path-tracing hot path: context and resource
+// management, conversion of the reference's flat scene arrays into the device layout (threaded breadth-first BVH,
+// leaf-ordered primitives, de-duplicated materials), pass scheduling and kernel launches.  The kernels themselves are
+// in mpt_kernels.h, their building blocks in mpt_device.h.
 //
-// Pipeline (MPT_PIPE_WAVEFRONT, the default):
-//   k_begin_pass        reset the pass descriptor
-//   repeat until the pass drains:
-//     k_step            persistent workgroups; each WAVE pulls 64-slot work items from per-XCD cursors.
-//                       An item is either 64 consecutive entries of the SoA input ray queue or 64 new
-//                       paths (primary rays are generated in registers and never touch HBM).  Per item:
-//                       closest hit against the LDS-staged threaded BVH, one bounce of shading, then the
-//                       surviving rays are compacted with a wave64 ballot + mbcnt prefix and appended to
-//                       the output queue with ONE atomic per wave (sharded counters).  Finished paths
-//                       write their clamped radiance to a per-path slot.
-//     k_advance         one wave: turn the output counters into the next iteration's descriptor
-//   k_resolve_*         per pixel: sum the per-path slots in sample order into the HDR sum (or apply the
-//                       reference's running-mean frame protocol, Fragment.metal:62-69)
+// One mpt_render = one pass per <= 2^30 paths: k_begin_pass, ONE k_wavelocal launch (default pipeline; the global
+// wavefront launches k_step + k_advance per bounce generation instead), k_resolve_sum, one host synchronisation.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile).  gfx950 only.
 #include <hip/hip_runtime.h>
 
@@ -29,729 +21,7 @@
 #include "mpt.h"
 #include "mpt_device.h"
 
-// Minimum waves per SIMD the trace kernels are compiled for (2nd __launch_bounds__ argument).  The kernels are
-// latency-bound (dependent LDS / L2 reads per BVH step): 8 waves/SIMD (<= 64 VGPRs, 2 x 1024-thread workgroups
-// per CU next to 2 x 57 KB of LDS) measured faster than 4-5 waves/SIMD at 81-83 VGPRs.
-#ifndef MPT_MIN_WAVES
-#define MPT_MIN_WAVES 8
-#endif
-
-// =====================================================================================================
-// device-side structures
-// =====================================================================================================
-struct QueueDev {  // struct-of-arrays ray queue, 16-byte records -> dwordx4 per lane, 1 KiB per wave access
-    float4* od;    // (o.x, o.y, o.z, d.x)
-    float4* dt;    // (d.y, d.z, thr.r, thr.g)
-    float4* tl;    // (thr.b, L.r, L.g, L.b)
-    uint2* ia;     // (path | bounce << 27, bits(L.a))
-};
-
-struct PassDesc {
-    // written by k_advance, read by k_step
-    uint32_t in_count[MPT_NSHARD];
-    uint32_t item_prefix[MPT_NSHARD + 1];  // queue items of shards [0,s) ; [NSHARD] = all queue items
-    uint32_t n_items;
-    uint32_t regen_base;
-    uint32_t range_end[MPT_NGROUP];
-    // pass state
-    uint32_t next_path, total_paths;
-    uint32_t slots_items;  // wavefront width in 64-slot items
-    uint32_t done, overflow, iterations;
-    unsigned long long paths, rays, node_visits, aabb_hits, prim_tests, node_iters, prim_iters, leaf_phases;
-};
-
-// Atomic counters live on lines of their own (MPT_CTR_STRIDE words apart): device-scope atomics are
-// executed at the memory side, and counters that share a line serialise there.
-#define MPT_CTR_STRIDE 1024u  // in uint32 words = 4 KiB
-#define MPT_CTR_CURSOR(g) ((g) * MPT_CTR_STRIDE)
-#define MPT_CTR_OUT(s) ((MPT_NGROUP + (s)) * MPT_CTR_STRIDE)
-#define MPT_CTR_WORDS ((MPT_NGROUP + MPT_NSHARD) * MPT_CTR_STRIDE)
-
-struct PassParams {
-    SceneDev scene;
-    uint32_t* ctr;               // work cursors [NGROUP] and output counters [NSHARD], padded
-    QueueDev q[2];
-    uint32_t shard_cap;
-    PassDesc* desc;
-    float4* slots;               // per-path final radiance (clamped), index = path
-    const uint32_t* pixel_seed;  // literal RNG: per-pixel u32 seed (host sin-hash, Fragment.metal:29)
-    // camera (mpt_uniforms)
-    F3 cam, first, vu, vv;
-    float W, H;
-    uint32_t width, height, tiles_x;
-    uint32_t S, sample_begin;    // samples per pixel in this pass, first sample index
-    uint32_t s_shift;            // log2(S) when S is a power of two, else 0xFF
-    const uint32_t* tile_xy;     // this rank's tiles in processing order: x | y << 16
-    uint32_t rank, nranks;
-    ShadeParams sp;
-    volatile uint32_t* host_done;
-};
-
-// Claim ranges of the single-launch pipelines: range g owns the rank's tiles k with k % MPT_NGROUP == g (every 8th
-// tile along the rows, so all ranges cover the image uniformly, progress at the same rate and run dry together).
-// A range is addressed by a virtual index v in [0, range_paths(g)): v -> tile k = (v / (S*64)) * 8 + g, sample
-// (v / 64) % S, lane v % 64.
-__device__ __forceinline__ uint32_t range_paths(uint32_t n_tiles, uint32_t S, uint32_t g) {
-    const uint32_t n_g = n_tiles > g ? (n_tiles - g + MPT_NGROUP - 1u) / MPT_NGROUP : 0u;
-    return n_g * S * 64u;
-}
-__device__ __forceinline__ uint32_t range_chunk_to_path_chunk(const PassParams& pp, uint32_t vchunk, uint32_t g) {
-    uint32_t tv, s;
-    if (pp.s_shift != 0xFFu) {
-        tv = vchunk >> pp.s_shift;
-        s = vchunk & (pp.S - 1u);
-    } else {
-        tv = vchunk / pp.S;
-        s = vchunk - tv * pp.S;
-    }
-    return (tv * MPT_NGROUP + g) * pp.S + s;  // chunk index in the pass's path-id space: tile * S + sample
-}
-
-// per-wave statistics: reduce over the 64 lanes, one atomic per counter per wave
-template <bool COUNT>
-__device__ __forceinline__ void flush_stats(PassDesc* desc, uint32_t n_rays, uint32_t n_paths, const WorkCount& wc) {
-    unsigned long long v[8] = {n_rays, n_paths, wc.node_visits, wc.aabb_hits, wc.prim_tests,
-                               wc.node_iters, wc.prim_iters, wc.outer_iters};
-    const int n = COUNT ? 8 : 2;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (k >= n) break;
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        unsigned long long* dst[8] = {&desc->rays, &desc->paths, &desc->node_visits, &desc->aabb_hits,
-                                      &desc->prim_tests, &desc->node_iters, &desc->prim_iters, &desc->leaf_phases};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k >= n) break;
-            if (v[k]) atomicAdd(dst[k], v[k]);
-        }
-    }
-}
-
-// path index -> pixel.  path = ((tile_local * S) + s) * 64 + lane; a wave = one 8x8 pixel tile.
-// tile_xy[tile_local] = tile x | tile y << 16 of this rank's tile_local-th tile: the host lays the rank's tiles out
-// in a strided (low-discrepancy) order so that any window of consecutive path ids mixes cheap (sky) and expensive
-// (mesh) tiles — with row-major order the expensive tiles cluster and the end of a pass is all slow work.
-__device__ __forceinline__ bool path_to_pixel(const PassParams& pp, uint32_t path, uint32_t& px, uint32_t& py,
-                                              uint32_t& s) {
-    const uint32_t lane = path & 63u, chunk = path >> 6;
-    uint32_t tl;
-    if (pp.s_shift != 0xFFu) {  // samples per pass is a power of two (the usual case): no division
-        tl = chunk >> pp.s_shift;
-        s = chunk & (pp.S - 1u);
-    } else {
-        tl = chunk / pp.S;
-        s = chunk - tl * pp.S;
-    }
-    const uint32_t xy = pp.tile_xy[tl];
-    px = (xy & 0xFFFFu) * 8u + (lane & 7u);
-    py = (xy >> 16) * 8u + (lane >> 3);
-    return px < pp.width && py < pp.height;
-}
-
-// Fragment.metal:29-42 — seed, sub-pixel jitter, primary ray.
-__device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, uint32_t sample,
-                                            PathState& ps, PathRngDev& g) {
-    float uvx = ((float)px + 0.5f) / pp.W, uvy = ((float)py + 0.5f) / pp.H;  // Vertex.metal:5-17
-    float xOff, yOff;
-    g.pixel = py * pp.width + px;
-    g.sample = sample;
-    if (pp.sp.rng_mode == 0) {
-        uint32_t seed = pp.pixel_seed[g.pixel];
-        xOff = (pcg_float(seed) - 0.5f) / pp.W;
-        seed = pcg_hash(seed);
-        yOff = (pcg_float(seed) - 0.5f) / pp.H;
-        seed = pcg_hash(seed);
-        g.lit_seed = seed;
-    } else {
-        U4 r = philox4x32_10(g.pixel, sample, 0xFFFFFFFFu, 0u, pp.sp.seed_lo, pp.sp.seed_hi);
-        xOff = (u01(r.x) - 0.5f) / pp.W;
-        yOff = (u01(r.y) - 0.5f) / pp.H;
-        g.lit_seed = 0;
-    }
-    F3 dir = (pp.first + (uvx + xOff) * pp.vu + (uvy + yOff) * pp.vv) - pp.cam;
-    ps.o = pp.cam;
-    ps.d = normalize3(dir);
-    ps.thr = f3(1, 1, 1);
-    ps.L = f3(0, 0, 0);
-    ps.La = 0.0f;
-    ps.bounce = 0;
-}
-
-// literal RNG: the seed entering rayColor is a pure function of the pixel; recompute it for bounce rays
-__device__ __forceinline__ void rng_for_path(const PassParams& pp, uint32_t path, PathRngDev& g) {
-    uint32_t px, py, s;
-    path_to_pixel(pp, path, px, py, s);
-    g.pixel = py * pp.width + px;
-    g.sample = pp.sample_begin + s;
-    g.lit_seed = 0;
-    if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
-}
-
-__device__ __forceinline__ void stage_nodes(const SceneDev& sc, float4* lds) {
-    const uint32_t n4 = sc.n_lds_nodes * 2u, p4 = sc.n_lds_prims * 3u;
-    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = sc.nodes[i];
-    for (uint32_t i = threadIdx.x; i < p4; i += blockDim.x) lds[n4 + i] = sc.prims[i];
-    for (uint32_t i = threadIdx.x; i < sc.n_lds_mats * 2u; i += blockDim.x) lds[n4 + p4 + i] = sc.mats[i];
-    __syncthreads();
-}
-
-// Wave-uniform work fetch: a wave claims a run of consecutive 64-slot items from its home group's
-// cursor (then steals from the other groups).  The run length is guided — remaining / (2 * waves) clamped
-// to [1, 16] — so the bulk of an iteration costs few atomics and the tail stays fine-grained.
-// (every lane of the wave is active here, so readfirstlane returns lane 0's value as an SGPR)
-__device__ __forceinline__ void fetch_items(uint32_t* ctr, const uint32_t* s_range_end, uint32_t home,
-                                            uint32_t waves_per_group, uint32_t& first, uint32_t& last) {
-    uint32_t f = MPT_NONE, l = 0;
-    if ((threadIdx.x & 63u) == 0) {
-        for (uint32_t t = 0; t < MPT_NGROUP; ++t) {
-            uint32_t g = (home + t) & (MPT_NGROUP - 1);
-            uint32_t end = s_range_end[g];
-            uint32_t cur = __hip_atomic_load(&ctr[MPT_CTR_CURSOR(g)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur >= end) continue;
-            uint32_t run = (end - cur) / (2u * waves_per_group);
-            run = run < 1u ? 1u : (run > 16u ? 16u : run);
-            uint32_t k = atomicAdd(&ctr[MPT_CTR_CURSOR(g)], run);
-            if (k < end) {
-                f = k;
-                l = (k + run < end) ? k + run : end;
-                break;
-            }
-        }
-    }
-    first = __builtin_amdgcn_readfirstlane(f);
-    last = __builtin_amdgcn_readfirstlane(l);
-}
-
-template <bool COUNT, bool ALL_LDS>
-__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uint32_t parity) {
-    extern __shared__ float4 lds_nodes[];
-    PassDesc* desc = pp.desc;
-    if (desc->n_items == 0) return;  // drained: iterations enqueued past the end of the pass cost a launch only
-    // iteration descriptor -> LDS, behind the node + primitive image (16-byte aligned)
-    uint32_t* s_prefix = (uint32_t*)(lds_nodes + 2 * pp.scene.n_lds_nodes + 3 * pp.scene.n_lds_prims + 2 * pp.scene.n_lds_mats);  // [NSHARD+1]
-    uint32_t* s_incount = s_prefix + (MPT_NSHARD + 1);                        // [NSHARD]
-    uint32_t* s_range_end = s_incount + MPT_NSHARD;                          // [NGROUP]
-    if (threadIdx.x <= MPT_NSHARD) s_prefix[threadIdx.x] = desc->item_prefix[threadIdx.x];
-    if (threadIdx.x < MPT_NSHARD) s_incount[threadIdx.x] = desc->in_count[threadIdx.x];
-    if (threadIdx.x < MPT_NGROUP) s_range_end[threadIdx.x] = desc->range_end[threadIdx.x];
-    stage_nodes(pp.scene, lds_nodes);
-
-    const QueueDev qin = pp.q[parity], qout = pp.q[parity ^ 1u];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t home = blockIdx.x & (MPT_NGROUP - 1);
-    const uint32_t nq_items = s_prefix[MPT_NSHARD];
-    const uint32_t total_paths = desc->total_paths;
-    const uint32_t regen_base = desc->regen_base;
-    uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
-
-    const uint32_t waves_per_group = (gridDim.x * (blockDim.x >> 6) + MPT_NGROUP - 1) / MPT_NGROUP;
-    uint32_t item = 0, item_last = 0;
-    for (;; ++item) {
-        if (item >= item_last) {
-            fetch_items(pp.ctr, s_range_end, home, waves_per_group, item, item_last);
-            if (item == MPT_NONE) break;
-        }
-        PathState ps;
-        PathRngDev g;
-        bool valid;
-        if (item < nq_items) {  // 64 entries of the input queue
-            uint32_t s = 0;
-#pragma unroll
-            for (uint32_t k = 1; k < MPT_NSHARD; ++k) s += (item >= s_prefix[k]) ? 1u : 0u;
-            const uint32_t idx = (item - s_prefix[s]) * 64u + lane;
-            valid = idx < s_incount[s];
-            if (valid) {
-                const uint32_t at = s * pp.shard_cap + idx;
-                const float4 a = qin.od[at], b = qin.dt[at], c = qin.tl[at];
-                const uint2 ia = qin.ia[at];
-                ps.o = f3(a.x, a.y, a.z);
-                ps.d = f3(a.w, b.x, b.y);
-                ps.thr = f3(b.z, b.w, c.x);
-                ps.L = f3(c.y, c.z, c.w);
-                ps.La = __uint_as_float(ia.y);
-                ps.path = ia.x & 0x07FFFFFFu;
-                ps.bounce = ia.x >> 27;
-                rng_for_path(pp, ps.path, g);
-            }
-        } else {  // 64 new paths: one 8x8 pixel tile at one sample index
-            ps.path = regen_base + (item - nq_items) * 64u + lane;
-            valid = ps.path < total_paths;
-            if (valid) {
-                uint32_t px, py, s;
-                valid = path_to_pixel(pp, ps.path, px, py, s);
-                if (valid) {
-                    gen_primary(pp, px, py, pp.sample_begin + s, ps, g);
-                    n_paths++;
-                }
-            }
-        }
-        bool alive = false;
-        if (valid) {
-            float t;
-            int prim;
-            closest_hit<COUNT, ALL_LDS>(pp.scene, (LdsNodes)lds_nodes, ps.o, ps.d, t, prim, wc);
-            n_rays++;
-            alive = shade_bounce(pp.scene, (LdsNodes)lds_nodes, pp.sp, g, ps, t, prim);
-            if (!alive)  // PathTracing.h:258 per-sample clamp
-                pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
-        }
-        // wave64 stream compaction: ballot + prefix popcount, one atomic per wave
-        const unsigned long long mask = __ballot(alive);
-        if (mask != 0ull) {
-            const uint32_t n = (uint32_t)__popcll(mask);
-            const uint32_t shard = item & (MPT_NSHARD - 1);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&pp.ctr[MPT_CTR_OUT(shard)], n);
-            base = __shfl(base, 0);
-            if (alive) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t idx = base + rank;
-                if (idx < pp.shard_cap) {
-                    const uint32_t at = shard * pp.shard_cap + idx;
-                    qout.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                    qout.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-                    qout.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                    qout.ia[at] = make_uint2(ps.path | (ps.bounce << 27), __float_as_uint(ps.La));
-                } else {
-                    desc->overflow = 1u;
-                }
-            }
-        }
-    }
-    flush_stats<COUNT>(desc, n_rays, n_paths, wc);
-}
-
-// one wave; lane 0 does the (tiny) serial work
-__device__ void advance_desc(PassDesc* d, uint32_t* ctr, volatile uint32_t* host_done) {
-    uint32_t items = 0;
-    for (uint32_t s = 0; s < MPT_NSHARD; ++s) {
-        uint32_t c = ctr[MPT_CTR_OUT(s)];
-        d->in_count[s] = c;
-        ctr[MPT_CTR_OUT(s)] = 0;
-        d->item_prefix[s] = items;
-        items += (c + 63u) >> 6;
-    }
-    d->item_prefix[MPT_NSHARD] = items;
-    uint32_t room = d->slots_items > items ? d->slots_items - items : 0u;
-    uint32_t left = (d->total_paths - d->next_path) >> 6;
-    uint32_t regen = room < left ? room : left;
-    d->regen_base = d->next_path;
-    d->next_path += regen * 64u;
-    uint32_t n = items + regen;
-    d->n_items = n;
-    for (uint32_t g = 0; g < MPT_NGROUP; ++g) {
-        uint32_t b = (uint32_t)(((unsigned long long)n * g) / MPT_NGROUP);
-        uint32_t e = (uint32_t)(((unsigned long long)n * (g + 1)) / MPT_NGROUP);
-        ctr[MPT_CTR_CURSOR(g)] = b;
-        d->range_end[g] = e;
-    }
-    d->done = (n == 0) ? 1u : 0u;
-    if (n != 0) d->iterations++;
-    if (host_done) *host_done = d->done | (d->overflow << 1);
-}
-
-__global__ void k_begin_pass(PassDesc* d, uint32_t* ctr, uint32_t total_paths, uint32_t slots_items,
-                             volatile uint32_t* host_done, int path_cursors) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (path_cursors) {  // single-launch pipelines: the cursors count path ids, one contiguous range per group
-        d->total_paths = total_paths;
-        d->overflow = 0;
-        for (uint32_t g = 0; g < MPT_NGROUP; ++g) ctr[MPT_CTR_CURSOR(g)] = 0u;
-        return;
-    }
-    for (uint32_t s = 0; s < MPT_NSHARD; ++s) ctr[MPT_CTR_OUT(s)] = 0;
-    d->next_path = 0;
-    d->total_paths = total_paths;
-    d->slots_items = slots_items;
-    d->iterations = 0;  // overflow stays sticky until the host has read it (collect_pass_stats)
-    advance_desc(d, ctr, host_done);
-}
-
-__global__ void k_advance(PassDesc* d, uint32_t* ctr, volatile uint32_t* host_done) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    advance_desc(d, ctr, host_done);
-}
-
-// Megakernel variant: one thread per path, whole bounce loop in registers (A/B baseline).
-template <bool COUNT, bool ALL_LDS>
-__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams pp) {
-    extern __shared__ float4 lds_nodes[];
-    stage_nodes(pp.scene, lds_nodes);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total_paths = pp.desc->total_paths;
-    const uint32_t waves_per_block = blockDim.x >> 6;
-    uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
-    for (uint32_t chunk = blockIdx.x * waves_per_block + (threadIdx.x >> 6); chunk * 64u < total_paths;
-         chunk += gridDim.x * waves_per_block) {
-        PathState ps;
-        PathRngDev g;
-        ps.path = chunk * 64u + lane;
-        uint32_t px, py, s;
-        if (!path_to_pixel(pp, ps.path, px, py, s)) continue;
-        gen_primary(pp, px, py, pp.sample_begin + s, ps, g);
-        n_paths++;
-        bool alive = true;
-        while (alive) {
-            float t;
-            int prim;
-            closest_hit<COUNT, ALL_LDS>(pp.scene, (LdsNodes)lds_nodes, ps.o, ps.d, t, prim, wc);
-            n_rays++;
-            alive = shade_bounce(pp.scene, (LdsNodes)lds_nodes, pp.sp, g, ps, t, prim);
-        }
-        pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
-    }
-    flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
-}
-
-__device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// Wave-local wavefront (MPT_PIPE_WAVELOCAL): the wavefront idea at wave scope, with rays sorted by remaining work.
-// Every persistent wave owns MPT_WL_LEVELS private rings of ray records (SoA, 16-byte fields, in global memory but
-// touched by this wave only) and runs full-width steps:
-//   ring k holds >= 64 rays -> pop 64, continue their closest-hit queries for at most budget[k] box-test loop trips,
-//                              shade the rays that finished (survivors are fresh rays -> ring 0), and PARK the rays
-//                              that are still traversing in ring k+1 with their exact traversal state (next node,
-//                              best t, best primitive).  The last ring has no budget.  Deepest ready ring first.
-//   no ring is ready        -> take the next 8x8-pixel tile sample (64 new paths), generate the primary rays in
-//                              registers, closest hit, one bounce of shading; survivors -> ring 0
-// Compaction into the rings is a wave64 ballot + mbcnt prefix; ring heads and counts are wave-uniform registers: no
-// kernel boundary, no shared counter, no atomic per step.
-// Why budgets: a wave runs as long as its slowest lane, and bounce rays are heavy-tailed on this kind of scene — 88 %
-// need <= 8 box tests, 10 % need 30-160 (they cross the mesh): a full wave of bounce rays used only 14 % of its
-// box-test lane slots.  Budgets 8/24/72/inf sort rays by remaining work (a radix sort on log3 of the work), so every
-// step runs rays of similar length (measured: box-test lane slots per ray 37.8 -> 17.8, VALU instructions per ray
-// 40 -> 24).  A parked ray resumes with exactly the state it stopped with and sees the
-// same sequence of tests: results are bit-identical.
-// Capacity: steps on rings never increase the total number of queued rays (64 out, <= 64 in) and a primary step
-// (+<= 64) runs only when every ring holds < 64, so the total never exceeds 64 * LEVELS + 64 = 384 < MPT_WL_RING.
-#define MPT_WL_LEVELS 5u
-#define MPT_WL_RING 512u       // records per ring
-#define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
-struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING]
-    float4* od;                // (o.xyz, d.x)
-    float4* dt;                // (d.y, d.z, thr.r, thr.g)
-    float4* tl;                // (thr.b, L.rgb)
-    uint4* ia;                 // (path, L.a bits, pixel, sample | bounce << 27)   path ids use all 32 bits here
-    uint4* tv;                 // rings >= 1: (next node, best t bits, best primitive, 0)
-};
-struct WaveBudgets {
-    uint32_t b[MPT_WL_LEVELS]; // box-test loop trips granted per step of ring k (last entry unused: unlimited)
-};
-
-template <bool COUNT, bool ALL_LDS>
-__global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp, WaveRings ring, WaveBudgets budgets,
-                                                                 uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
-    extern __shared__ float4 lds_nodes_raw[];
-    stage_nodes(pp.scene, lds_nodes_raw);
-    const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total_paths = pp.desc->total_paths;
-    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t wbase = wave_id * (MPT_WL_LEVELS * MPT_WL_RING);
-    const uint32_t M = MPT_WL_RING - 1u;
-    uint32_t head[MPT_WL_LEVELS], cnt[MPT_WL_LEVELS];  // wave-uniform ring state (fully unrolled accesses)
-#pragma unroll
-    for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) head[k] = cnt[k] = 0;
-    uint32_t cur = 0, end = 0;     // wave-uniform private range of path ids (multiples of 64)
-    const uint32_t n_tiles = total_paths / (pp.S * 64u);  // this rank's tiles
-    const uint32_t waves_per_group = (n_waves + MPT_NGROUP - 1u) / MPT_NGROUP;
-    uint32_t grp = blockIdx.x & (MPT_NGROUP - 1u);     // range this wave currently claims from
-    uint32_t seen = 0;                                 // cursor value (virtual index) at this wave's previous claim
-    bool exhausted = false;
-    uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
-#ifdef MPT_DEBUG_WAVE_TIMES
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long t_exh = 0ull;
-#endif
-    for (;;) {
-        // ---- step choice: deepest ring with a full wave of rays; else new paths; else drain ----------------------
-        int level = -1;  // -1 = primary step
-#pragma unroll
-        for (int k = (int)MPT_WL_LEVELS - 1; k >= 0; --k)
-            if (level < 0 && cnt[k] >= 64u) level = k;
-        if (level < 0) {
-            if (!exhausted && cur == end) {
-                // Guided self-scheduling of path ids.  The pass's tiles are dealt to MPT_NGROUP interleaved ranges,
-                // each with its own cursor on its own line (a single cursor saturates at ~88 claims/us: in the sky
-                // part of the image a step takes ~1 us and 8192 waves would queue on it).  A wave claims from its
-                // home range (blockIdx % 8: the blocks of one XCD under round-robin placement), then steals from the
-                // next ranges.  Claim size = remaining_in_range / (wl_div * waves_per_range) rounded to whole 64-path
-                // tile samples and clamped to [wl_min, wl_block]: few atomics while there is plenty of work, fine grain
-                // at the end (tile samples differ ~5x in cost between sky and geometry; with remaining/(2*waves) the
-                // last wave finished 23 ms after the first, with /16 within ~1 ms).  `seen` is the cursor value of
-                // this wave's previous claim: an extra load of the hot cursor line before the atomic made the kernel
-                // 4x slower (loads of a line under atomic fire serialise at the memory side).
-                uint32_t k = 0, blk = 0, rend = 0;
-                bool got = false;
-                if (lane == 0) {
-                    for (uint32_t t = 0; t < MPT_NGROUP && !got; ++t) {
-                        const uint32_t re = range_paths(n_tiles, pp.S, grp);
-                        const uint32_t left = seen < re ? re - seen : 0u;
-                        blk = (left / (wl_div * waves_per_group)) & ~63u;
-                        blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
-                        k = atomicAdd(&pp.ctr[MPT_CTR_CURSOR(grp)], blk);
-                        if (k < re) {
-                            got = true;
-                            rend = re;
-                        } else {
-                            grp = (grp + 1u) & (MPT_NGROUP - 1u);
-                            seen = 0;
-                        }
-                    }
-                }
-                got = __builtin_amdgcn_readfirstlane((int)got) != 0;
-                k = __builtin_amdgcn_readfirstlane(k);
-                blk = __builtin_amdgcn_readfirstlane(blk);
-                rend = __builtin_amdgcn_readfirstlane(rend);
-                grp = __builtin_amdgcn_readfirstlane(grp);
-                seen = k;
-                if (!got) {
-                    exhausted = true;
-                } else {
-                    cur = k;
-                    end = (k + blk < rend) ? k + blk : rend;
-                }
-            }
-            if (exhausted) {
-                // Drain: no new paths and no ring holds a full wave.  What is left in ALL rings is merged into
-                // full-width steps without a budget (deepest ring first), instead of one partial step per ring and
-                // bounce generation: with per-ring partial steps every wave spent 1.4-2.2 ms draining.
-                uint32_t total = 0;
-#pragma unroll
-                for (int k = 0; k < (int)MPT_WL_LEVELS; ++k) total += cnt[k];
-                if (total == 0u) break;
-                level = (int)MPT_WL_LEVELS;  // merged drain step
-            }
-        }
-        PathState ps;
-        PathRngDev g;
-        bool valid = false;
-        uint32_t node = 0;
-        float best_t = INFINITY;
-        int best_prim = -1;
-        uint32_t budget = 0xFFFFFFFFu;
-        bool fresh = false;  // this lane starts a new closest-hit query (primary ray or ring-0 record)
-        if (level < 0) {
-            fresh = true;
-            ps.path = range_chunk_to_path_chunk(pp, cur >> 6, grp) * 64u + lane;  // cur is a virtual index of range grp
-            cur += 64u;
-            uint32_t px, py, sidx;
-            if (path_to_pixel(pp, ps.path, px, py, sidx)) {
-                gen_primary(pp, px, py, pp.sample_begin + sidx, ps, g);
-                valid = true;
-                n_paths++;
-            }
-        } else {
-            // lanes -> ring records.  Normal step: 64 records of ring `level`.  Merged drain step: up to 64 records
-            // taken from all rings, deepest first (lane ranges [lo_k, lo_k + take_k) per ring).
-            uint32_t my_ring = 0, my_off = 0;
-            bool take = false;
-            uint32_t assigned = 0;
-#pragma unroll
-            for (int k = (int)MPT_WL_LEVELS - 1; k >= 0; --k) {
-                const bool use = (level == (int)MPT_WL_LEVELS) || (level == k);
-                uint32_t tk = use ? cnt[k] : 0u;
-                tk = tk < 64u - assigned ? tk : 64u - assigned;
-                if (lane >= assigned && lane < assigned + tk) {
-                    take = true;
-                    my_ring = (uint32_t)k;
-                    my_off = (head[k] + (lane - assigned)) & M;
-                }
-                if (level == k) budget = budgets.b[k];
-                head[k] = (head[k] + tk) & M;
-                cnt[k] -= tk;
-                assigned += tk;
-            }
-            if (take) {
-                const uint32_t at = wbase + my_ring * MPT_WL_RING + my_off;
-                const float4 a = ring.od[at], b = ring.dt[at], cc = ring.tl[at];
-                const uint4 ia = ring.ia[at];
-                ps.o = f3(a.x, a.y, a.z);
-                ps.d = f3(a.w, b.x, b.y);
-                ps.thr = f3(b.z, b.w, cc.x);
-                ps.L = f3(cc.y, cc.z, cc.w);
-                ps.La = __uint_as_float(ia.y);
-                ps.path = ia.x;
-                ps.bounce = ia.w >> 27;
-                g.pixel = ia.z;
-                g.sample = ia.w & 0x07FFFFFFu;
-                g.lit_seed = 0;
-                if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
-                if (my_ring > 0u) {
-                    const uint4 tv = ring.tv[at];
-                    node = tv.x;
-                    best_t = __uint_as_float(tv.y);
-                    best_prim = (int)tv.z;
-                } else {
-                    fresh = true;
-                }
-                valid = true;
-            }
-        }
-        const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS - 1;
-        bool alive = false, parked = false;
-        if (valid) {
-            bool done;
-            if (budgeted)
-                done = closest_hit_resume<COUNT, ALL_LDS, true>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
-                                                               budget, wc);
-            else
-                done = closest_hit_resume<COUNT, ALL_LDS, false>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
-                                                                0xFFFFFFFFu, wc);
-            if (fresh) n_rays++;  // a resumed query was counted when it started
-            if (done) {
-                alive = shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, best_prim);
-                if (!alive)
-                    pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
-            } else {
-                parked = true;
-            }
-        }
-        const unsigned long long am = __ballot(alive), pm = __ballot(parked);
-        if (am != 0ull) {  // survivors are fresh rays -> ring 0
-            if (alive) {
-                const uint32_t at = wbase + ((head[0] + cnt[0] + wave_rank(am)) & M);
-                ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-                ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
-            }
-            cnt[0] += (uint32_t)__popcll(am);
-        }
-        if (pm != 0ull) {  // unfinished queries -> next ring, with their traversal state (only from budgeted steps)
-            uint32_t h = 0, c = 0;
-#pragma unroll
-            for (int k = 1; k < (int)MPT_WL_LEVELS; ++k)
-                if (k == level + 1) {
-                    h = head[k];
-                    c = cnt[k];
-                }
-            if (parked) {
-                const uint32_t at = wbase + (uint32_t)(level + 1) * MPT_WL_RING + ((h + c + wave_rank(pm)) & M);
-                ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-                ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
-                ring.tv[at] = make_uint4(node, __float_as_uint(best_t), (uint32_t)best_prim, 0u);
-            }
-#pragma unroll
-            for (int k = 1; k < (int)MPT_WL_LEVELS; ++k)
-                if (k == level + 1) cnt[k] = c + (uint32_t)__popcll(pm);
-        }
-        uint32_t worst = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) worst = cnt[k] > worst ? cnt[k] : worst;
-        if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (see capacity note above)
-#ifdef MPT_DEBUG_WAVE_TIMES
-        if (exhausted && t_exh == 0ull) t_exh = __builtin_amdgcn_s_memrealtime();
-#endif
-    }
-#ifdef MPT_DEBUG_WAVE_TIMES  // diagnostics build: per-wave (start, cursor exhausted, end) timestamps, 100 MHz ticks
-    if (lane == 0) {
-        unsigned long long* dbg = (unsigned long long*)(ring.tv + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING);
-        dbg[3 * wave_id] = t_start;
-        dbg[3 * wave_id + 1] = t_exh;
-        dbg[3 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
-    flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
-}
-
-// sum[pixel] += sum over the pass's samples (in sample order) of the clamped per-sample colour
-__global__ void k_resolve_sum(PassParams pp, float4* sum, uint32_t n_local_tiles) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_local_tiles * 64u) return;
-    uint32_t tl = i >> 6, lane = i & 63u;
-    uint32_t px, py, s0;
-    if (!path_to_pixel(pp, (tl * pp.S) * 64u + lane, px, py, s0)) return;
-    float4 acc = sum[py * pp.width + px];
-    for (uint32_t s = 0; s < pp.S; ++s) {
-        float4 v = pp.slots[(tl * pp.S + s) * 64u + lane];
-        acc.x += v.x;
-        acc.y += v.y;
-        acc.z += v.z;
-        acc.w += v.w;
-    }
-    sum[py * pp.width + px] = acc;
-}
-
-// Fragment.metal:23-27,62-69 — running mean with the frameCount+1 weight and the clamp.
-__global__ void k_resolve_frame(PassParams pp, const float4* last, float4* cur, uint32_t n_local_tiles,
-                                unsigned long long frameCount) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_local_tiles * 64u) return;
-    uint32_t tl = i >> 6, lane = i & 63u;
-    uint32_t px, py, s0;
-    if (!path_to_pixel(pp, tl * 64u + lane, px, py, s0)) return;
-    float4 c = pp.slots[tl * 64u + lane];
-    float4 l = make_float4(0, 0, 0, 0);
-    if (frameCount != 0) l = last[py * pp.width + px];
-    unsigned long long fc = frameCount + 1ull;
-    float w = (float)(fc - 1ull), fcf = (float)fc;
-    float4 o;
-    o.x = clamp01((c.x + l.x * w) / fcf);
-    o.y = clamp01((c.y + l.y * w) / fcf);
-    o.z = clamp01((c.z + l.z * w) / fcf);
-    o.w = clamp01((c.w + l.w * w) / fcf);
-    cur[py * pp.width + px] = o;
-}
-
-// unit-test kernels ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_trace_rays(SceneDev sc, const float* o, const float* d, uint32_t n,
-                                                     float* t_out, int* prim_out, float* n_out, int* front_out) {
-    extern __shared__ float4 lds_nodes[];
-    stage_nodes(sc, lds_nodes);
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    F3 ro = f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    float t;
-    int prim;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
-    closest_hit<false, false>(sc, (LdsNodes)lds_nodes, ro, rd, t, prim, wc);
-    t_out[i] = t;
-    if (prim >= 0) {
-        HitInfo h = finish_hit(sc, (LdsNodes)lds_nodes, ro, rd, t, prim);
-        prim_out[i] = h.orig_id;
-        n_out[3 * i] = h.normal.x;
-        n_out[3 * i + 1] = h.normal.y;
-        n_out[3 * i + 2] = h.normal.z;
-        front_out[i] = h.front ? 1 : 0;
-    } else {
-        prim_out[i] = -1;
-        n_out[3 * i] = n_out[3 * i + 1] = n_out[3 * i + 2] = 0.0f;
-        front_out[i] = 0;
-    }
-}
-__global__ void k_kat_pcg(const uint32_t* s, uint32_t n, uint32_t* h, float* f) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        h[i] = pcg_hash(s[i]);
-        f[i] = pcg_float(s[i]);
-    }
-}
-__global__ void k_kat_philox(const uint32_t* c, const uint32_t* k, uint32_t n, uint32_t* o) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        U4 r = philox4x32_10(c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3], k[2 * i], k[2 * i + 1]);
-        o[4 * i] = r.x;
-        o[4 * i + 1] = r.y;
-        o[4 * i + 2] = r.z;
-        o[4 * i + 3] = r.w;
-    }
-}
-__global__ void k_kat_sincos(const float* u, uint32_t n, float* s, float* c) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sincos_2pi(u[i], s[i], c[i]);
-}
+#include "mpt_kernels.h"
 
 // =====================================================================================================
 // host side of the C ABI
