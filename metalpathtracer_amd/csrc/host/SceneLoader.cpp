@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <sstream>
 #include <utility>
 #include <vector>
@@ -122,51 +123,245 @@ struct Mesh {
     std::vector<mpt::uint3> triangles;
 };
 
-bool readObj(const std::string& path, Mesh& mesh, std::string& log) {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) {
-        log += "Failed to load OBJ: " + path + "\n";
+// Reads the vertex and face statements of a Wavefront OBJ the way the reference's call
+// tinyobj::LoadObj(&attrib, &shapes, &materials, &warn, &err, path) does (R/Scene/SceneLoader.cpp:26,
+// tinyobjloader 2.0.0 defaults: triangulate = true), then filters like SceneLoader.cpp:40-68:
+//   - statements end at \n, \r\n or a lone \r; trailing blanks are dropped; `#` ends a face statement;
+//   - a corner is `i`, `i/j`, `i//k` or `i/j/k` read with atoi; vertex index 0 or a relative index that reaches
+//     before the first element makes the whole file unreadable (the library returns false);
+//   - faces wait in their group until `g <name>`, `o <name>` or the end of the file and are triangulated against
+//     the vertices read by then: triangles as they are; quads along the shorter diagonal (0-2 only if strictly
+//     shorter than 1-3, a quad with an unread vertex is dropped); larger polygons by the library's ear clipping
+//     in the plane of two coordinate axes chosen from the first non-degenerate corner;
+//   - triangles naming a vertex beyond the final count are reported and skipped.
+// Material libraries are not read (the reference never uses them; with one present tinyobj would also flush a
+// group at a material change, which only matters for faces that name vertices defined later in the file).
+class ObjReader {
+public:
+    ObjReader(Mesh& mesh, std::string& log) : mesh_(mesh), log_(log) {}
+
+    bool read(const std::string& path) {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) return unreadable(path);
+        std::stringstream whole;
+        whole << in.rdbuf();
+        const std::string text = whole.str();
+        size_t at = 0;
+        std::string st;
+        while (at < text.size()) {
+            size_t stop = text.find_first_of("\r\n", at);
+            if (stop == std::string::npos) stop = text.size();
+            st.assign(text, at, stop - at);
+            at = stop + 1;
+            if (stop < text.size() && text[stop] == '\r' && at < text.size() && text[at] == '\n') ++at;
+            const size_t last = st.find_last_not_of(" \t");
+            st.erase(last == std::string::npos ? 0 : last + 1);
+            if (!statement(st.c_str())) return unreadable(path);
+        }
+        flushGroup();
+        const size_t nv = coords_.size() / 3;
+        mesh_.vertices.reserve(nv);
+        for (size_t i = 0; i < nv; ++i) mesh_.vertices.emplace_back(coords_[3 * i], coords_[3 * i + 1], coords_[3 * i + 2]);
+        for (size_t i = 0; i + 2 < corners_.size(); i += 3) {
+            if (corners_[i] >= nv || corners_[i + 1] >= nv || corners_[i + 2] >= nv) {
+                log_ += "Invalid triangle indices\n";
+                continue;
+            }
+            mpt::uint3 t;
+            t.x = corners_[i];
+            t.y = corners_[i + 1];
+            t.z = corners_[i + 2];
+            mesh_.triangles.push_back(t);
+        }
+        char msg[128];
+        std::snprintf(msg, sizeof msg, "Loaded OBJ: %zu vertices, %zu triangles\n", mesh_.vertices.size(),
+                      mesh_.triangles.size());
+        log_ += msg;
+        return true;
+    }
+
+private:
+    static bool blank(char c) { return c == ' ' || c == '\t'; }
+
+    bool unreadable(const std::string& path) {
+        log_ += "Failed to load OBJ: " + path + "\n";
         return false;
     }
-    std::string line;
-    std::vector<long> corner;
-    while (std::getline(in, line)) {
-        const char* p = line.c_str();
+
+    // zero-based index from an OBJ index; `zeroOk` is true for the normal/texcoord fields
+    static bool resolve(int raw, size_t count, bool zeroOk, long& out) {
+        if (raw > 0) {
+            out = raw - 1;
+            return true;
+        }
+        if (raw == 0) {
+            out = -1;
+            return zeroOk;
+        }
+        out = static_cast<long>(count) + raw;
+        return out >= 0;
+    }
+
+    bool corner(const char*& p, long& vertex) {
+        long ignored = 0;
+        if (!resolve(std::atoi(p), coords_.size() / 3, false, vertex)) return false;
+        p += std::strcspn(p, "/ \t\r");
+        if (*p != '/') return true;
+        ++p;
+        if (*p == '/') {
+            ++p;
+            if (!resolve(std::atoi(p), normals_, true, ignored)) return false;
+            p += std::strcspn(p, "/ \t\r");
+            return true;
+        }
+        if (!resolve(std::atoi(p), texcoords_, true, ignored)) return false;
+        p += std::strcspn(p, "/ \t\r");
+        if (*p != '/') return true;
+        ++p;
+        if (!resolve(std::atoi(p), normals_, true, ignored)) return false;
+        p += std::strcspn(p, "/ \t\r");
+        return true;
+    }
+
+    bool statement(const char* p) {
         p += std::strspn(p, " \t");
-        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+        const char k = p[0];
+        if (k == 'v' && blank(p[1])) {
             p += 1;
-            float x = objReal(p), y = objReal(p), z = objReal(p);
-            mesh.vertices.emplace_back(x, y, z);
-        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
-            p += 1;
-            corner.clear();
-            const long nv = static_cast<long>(mesh.vertices.size());
-            for (;;) {
-                p += std::strspn(p, " \t");
-                if (*p == '\0' || *p == '\r' || *p == '\n') break;
-                long raw = std::atol(p);                  // "a", "a/b", "a//c", "a/b/c": the vertex index leads
-                corner.push_back(raw > 0 ? raw - 1 : (raw < 0 ? nv + raw : -1));
-                p += std::strcspn(p, " \t\r\n");
+            const float x = objReal(p), y = objReal(p), z = objReal(p);
+            coords_.push_back(x);
+            coords_.push_back(y);
+            coords_.push_back(z);
+        } else if (k == 'v' && p[1] == 'n' && blank(p[2])) {
+            ++normals_;
+        } else if (k == 'v' && p[1] == 't' && blank(p[2])) {
+            ++texcoords_;
+        } else if ((k == 'f' || k == 'l' || k == 'p') && blank(p[1])) {
+            p += 2;
+            p += std::strspn(p, " \t");
+            std::vector<long> poly;
+            while (*p != '\0' && *p != '\r' && *p != '\n' && *p != '#') {
+                long v = -1;
+                if (!corner(p, v)) return false;
+                poly.push_back(v);
+                p += std::strspn(p, " \t\r");
             }
-            for (size_t k = 2; k < corner.size(); ++k) {  // triangle fan (tinyobj triangulate = true)
-                const long a = corner[0], b = corner[k - 1], c = corner[k];
-                if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv) {
-                    log += "Invalid triangle indices\n";
-                    continue;
-                }
-                mpt::uint3 t;
-                t.x = static_cast<uint32_t>(a);
-                t.y = static_cast<uint32_t>(b);
-                t.z = static_cast<uint32_t>(c);
-                mesh.triangles.push_back(t);
-            }
+            if (k == 'f') pending_.push_back(std::move(poly));
+        } else if ((k == 'g' || k == 'o') && blank(p[1])) {
+            flushGroup();
+        }
+        return true;
+    }
+
+    void flushGroup() {
+        for (const std::vector<long>& poly : pending_) {
+            if (poly.size() == 3) tri(poly[0], poly[1], poly[2]);
+            else if (poly.size() == 4) quad(poly);
+            else if (poly.size() > 4) clipEars(poly);
+        }
+        pending_.clear();
+    }
+
+    void tri(long a, long b, long c) {
+        corners_.push_back(static_cast<uint32_t>(a));
+        corners_.push_back(static_cast<uint32_t>(b));
+        corners_.push_back(static_cast<uint32_t>(c));
+    }
+
+    bool known(long i) const { return 3 * static_cast<size_t>(i) + 2 < coords_.size(); }
+    const float* at(long i) const { return &coords_[3 * static_cast<size_t>(i)]; }
+
+    void quad(const std::vector<long>& q) {
+        for (long i : q)
+            if (!known(i)) return;
+        auto span2 = [&](long a, long b) {
+            const float dx = at(b)[0] - at(a)[0], dy = at(b)[1] - at(a)[1], dz = at(b)[2] - at(a)[2];
+            return dx * dx + dy * dy + dz * dz;
+        };
+        if (span2(q[0], q[2]) < span2(q[1], q[3])) {
+            tri(q[0], q[1], q[2]);
+            tri(q[0], q[2], q[3]);
+        } else {
+            tri(q[0], q[1], q[3]);
+            tri(q[1], q[2], q[3]);
         }
     }
-    char msg[128];
-    std::snprintf(msg, sizeof msg, "Loaded OBJ: %zu vertices, %zu triangles\n", mesh.vertices.size(), mesh.triangles.size());
-    log += msg;
-    return true;
-}
+
+    // crossing-number test of (tx, ty) against the triangle (x[], y[])
+    static bool insideTriangle(const float x[3], const float y[3], float tx, float ty) {
+        bool odd = false;
+        for (int i = 0, j = 2; i < 3; j = i++)
+            if ((y[i] > ty) != (y[j] > ty) && tx < (x[j] - x[i]) * (ty - y[i]) / (y[j] - y[i]) + x[i]) odd = !odd;
+        return odd;
+    }
+
+    void clipEars(const std::vector<long>& poly) {
+        const size_t n = poly.size(), nc = coords_.size();
+        size_t ua = 1, ub = 2;  // the two coordinate axes the polygon is flattened onto
+        for (size_t k = 0; k < n; ++k) {
+            const long i0 = poly[k], i1 = poly[(k + 1) % n], i2 = poly[(k + 2) % n];
+            if (!known(i0) || !known(i1) || !known(i2)) continue;
+            const float ex = at(i1)[0] - at(i0)[0], ey = at(i1)[1] - at(i0)[1], ez = at(i1)[2] - at(i0)[2];
+            const float fx = at(i2)[0] - at(i1)[0], fy = at(i2)[1] - at(i1)[1], fz = at(i2)[2] - at(i1)[2];
+            const float nx = std::fabs(ey * fz - ez * fy);
+            const float ny = std::fabs(ez * fx - ex * fz);
+            const float nz = std::fabs(ex * fy - ey * fx);
+            const float tiny = std::numeric_limits<float>::epsilon();
+            if (nx > tiny || ny > tiny || nz > tiny) {
+                if (!(nx > ny && nx > nz)) {
+                    ua = 0;
+                    if (nz > nx && nz > ny) ub = 1;
+                }
+                break;
+            }
+        }
+        std::vector<long> ring = poly;
+        size_t probe = 0, tries = n, lastSize = n;
+        while (ring.size() > 3 && tries > 0) {
+            const size_t m = ring.size();
+            if (probe >= m) probe -= m;
+            if (lastSize != m) {
+                lastSize = m;
+                tries = m;
+            } else {
+                --tries;
+            }
+            long id[3];
+            float x[3], y[3];
+            for (size_t k = 0; k < 3; ++k) {
+                id[k] = ring[(probe + k) % m];
+                const size_t base = 3 * static_cast<size_t>(id[k]);
+                const bool have = base + ua < nc && base + ub < nc;
+                x[k] = have ? coords_[base + ua] : 0.0f;
+                y[k] = have ? coords_[base + ub] : 0.0f;
+            }
+            const float turn = (x[1] - x[0]) * (y[2] - y[1]) - (y[1] - y[0]) * (x[2] - x[1]);
+            const float sign = (x[0] * y[1] - y[0] * x[1]) * 0.5f;  // the library's orientation term: two vertices only
+            bool ear = !(turn * sign < 0.0f);
+            for (size_t o = 3; ear && o < m; ++o) {
+                const size_t base = 3 * static_cast<size_t>(ring[(probe + o) % m]);
+                if (base + ua >= nc || base + ub >= nc) continue;
+                if (insideTriangle(x, y, coords_[base + ua], coords_[base + ub])) ear = false;
+            }
+            if (!ear) {
+                ++probe;
+                continue;
+            }
+            tri(id[0], id[1], id[2]);
+            ring.erase(ring.begin() + static_cast<long>((probe + 1) % m));
+        }
+        if (ring.size() == 3) tri(ring[0], ring[1], ring[2]);
+    }
+
+    Mesh& mesh_;
+    std::string& log_;
+    std::vector<float> coords_;
+    size_t normals_ = 0, texcoords_ = 0;
+    std::vector<std::vector<long>> pending_;
+    std::vector<uint32_t> corners_;
+};
+
+bool readObj(const std::string& path, Mesh& mesh, std::string& log) { return ObjReader(mesh, log).read(path); }
 
 // ------------------------------------------------------------------------------------------ XML subset
 struct Element {

@@ -638,9 +638,10 @@ static int ensure_tile_order(mpt_ctx* ctx, uint32_t rank, uint32_t nranks, uint3
     return MPT_OK;
 }
 
-static int ensure_workspace(mpt_ctx* ctx, uint32_t slots_items, uint64_t pass_paths) {
+// The global ray queues exist only for the wavefront pipeline; the other two never touch them.
+static int ensure_workspace(mpt_ctx* ctx, uint32_t slots_items, uint64_t pass_paths, bool need_queues) {
     uint32_t cap = ((slots_items + MPT_NSHARD - 1) / MPT_NSHARD + 2) * 64u;
-    if (cap > ctx->shard_cap) {
+    if (need_queues && cap > ctx->shard_cap) {
         free_queues(ctx);
         size_t n = (size_t)cap * MPT_NSHARD;
         for (int i = 0; i < 2; ++i) {
@@ -697,7 +698,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     uint32_t slots_items = std::max<uint32_t>(64, (slots + 63) / 64);
     if ((uint64_t)slots_items * 64 > pass_paths + 64) slots_items = (uint32_t)((pass_paths + 63) / 64);
     if (slots_items < 8) slots_items = 8;
-    int rc = ensure_workspace(ctx, slots_items, std::max<uint64_t>(pass_paths, 64));
+    int rc = ensure_workspace(ctx, slots_items, std::max<uint64_t>(pass_paths, 64), p->pipeline == MPT_PIPE_WAVEFRONT);
     if (rc) return rc;
     if (p->rng_mode == MPT_RNG_LITERAL && (rc = ensure_pixel_seeds(ctx))) return rc;
 

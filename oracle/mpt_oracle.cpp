@@ -348,50 +348,257 @@ static float tinyobj_parse_real(const char** tok) {  // tiny_obj_loader.h:1030-1
     return (float)val;
 }
 
-// OBJ subset the reference path exercises (SceneLoader.cpp:20-73): `v x y z`, `f i[/j][/k] ...`
-// with 1-based / negative indices; polygons are fan-triangulated (tinyobj triangulate=true;
-// its ear-clipping for concave n-gons is NOT restated — triangles and convex quads only).
+// ---- OBJ ingest: restatement of what tinyobj::LoadObj (tinyobjloader 2.0.0, vendored at
+// R/tiny_obj_loader.h, called with its defaults at R/Scene/SceneLoader.cpp:26) does to the vertex and
+// face statements, followed by the reference's own filtering (SceneLoader.cpp:40-68).  Checked against the
+// real library by tests/test_ingest_vs_ref.py (oracle/_ref).
+//
+//  * `v x y z`: floats via tinyobj's own parser (tinyobj_parse_real above).
+//  * `f`/`l`/`p` corners `i`, `i/j`, `i//k`, `i/j/k`: atoi; a vertex index of 0, or a relative (negative)
+//    index reaching before the first element, fails the WHOLE file (tiny_obj_loader.h:819-850,1188-1239),
+//    which the reference reports as "Failed to load OBJ" and carries on with no triangles.
+//  * faces are triangulated when their group is flushed (at `g`, `o`, end of file) against the vertices
+//    read so far: 3 corners -> as is; 4 corners -> split along the shorter diagonal, 0-2 only when strictly
+//    shorter (h:1510-1608); 5+ corners -> the library's ear clipping on the two axes picked from the first
+//    non-degenerate corner (h:1738-1962), including its quirks (the `area` term uses two vertices only).
+//  * the reference then drops triangles with an index >= the final vertex count (SceneLoader.cpp:62-66).
+struct ObjFace {
+    std::vector<int> v;
+};
+
+// point-in-triangle by crossing number, float arithmetic in the library's order (h:1440-1450)
+static bool obj_pnpoly3(const float* px, const float* py, float tx, float ty) {
+    bool inside = false;
+    for (int i = 0, j = 2; i < 3; j = i++) {
+        if (((py[i] > ty) != (py[j] > ty)) && (tx < (px[j] - px[i]) * (ty - py[i]) / (py[j] - py[i]) + px[i]))
+            inside = !inside;
+    }
+    return inside;
+}
+
+static void obj_emit(std::vector<uint32_t>& out, int a, int b, int c) {
+    out.push_back((uint32_t)a);
+    out.push_back((uint32_t)b);
+    out.push_back((uint32_t)c);
+}
+
+static void obj_triangulate(const ObjFace& face, const std::vector<float>& v, std::vector<uint32_t>& out) {
+    const size_t n = face.v.size();
+    const size_t vs = v.size();
+    if (n < 3) return;  // "Degenerated face"
+    if (n == 3) {
+        obj_emit(out, face.v[0], face.v[1], face.v[2]);
+        return;
+    }
+    auto in_range = [&](int i) { return 3 * (size_t)i + 2 < vs; };
+    if (n == 4) {
+        const int* q = face.v.data();
+        if (!in_range(q[0]) || !in_range(q[1]) || !in_range(q[2]) || !in_range(q[3])) return;
+        const float* p0 = &v[3 * (size_t)q[0]];
+        const float* p1 = &v[3 * (size_t)q[1]];
+        const float* p2 = &v[3 * (size_t)q[2]];
+        const float* p3 = &v[3 * (size_t)q[3]];
+        float ax = p2[0] - p0[0], ay = p2[1] - p0[1], az = p2[2] - p0[2];
+        float bx = p3[0] - p1[0], by = p3[1] - p1[1], bz = p3[2] - p1[2];
+        float d02 = ax * ax + ay * ay + az * az;
+        float d13 = bx * bx + by * by + bz * bz;
+        if (d02 < d13) {
+            obj_emit(out, q[0], q[1], q[2]);
+            obj_emit(out, q[0], q[2], q[3]);
+        } else {
+            obj_emit(out, q[0], q[1], q[3]);
+            obj_emit(out, q[1], q[2], q[3]);
+        }
+        return;
+    }
+    // 5+ corners.  Projection axes from the first corner whose edge cross product is not ~0.
+    size_t ax0 = 1, ax1 = 2;
+    for (size_t k = 0; k < n; ++k) {
+        int i0 = face.v[k % n], i1 = face.v[(k + 1) % n], i2 = face.v[(k + 2) % n];
+        if (!in_range(i0) || !in_range(i1) || !in_range(i2)) continue;
+        const float* a = &v[3 * (size_t)i0];
+        const float* b = &v[3 * (size_t)i1];
+        const float* c = &v[3 * (size_t)i2];
+        float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2];
+        float e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+        float cx = std::fabs(e0y * e1z - e0z * e1y);
+        float cy = std::fabs(e0z * e1x - e0x * e1z);
+        float cz = std::fabs(e0x * e1y - e0y * e1x);
+        const float eps = std::numeric_limits<float>::epsilon();
+        if (cx > eps || cy > eps || cz > eps) {
+            if (!(cx > cy && cx > cz)) {
+                ax0 = 0;
+                if (cz > cx && cz > cy) ax1 = 1;
+            }
+            break;
+        }
+    }
+    std::vector<int> rest = face.v;
+    size_t guess = 0, budget = n, last_size = n;
+    while (rest.size() > 3 && budget > 0) {
+        const size_t m = rest.size();
+        if (guess >= m) guess -= m;
+        if (last_size != m) {
+            last_size = m;
+            budget = m;
+        } else {
+            --budget;
+        }
+        int ind[3];
+        float px[3], py[3];
+        for (size_t k = 0; k < 3; ++k) {
+            ind[k] = rest[(guess + k) % m];
+            size_t base = 3 * (size_t)ind[k];
+            if (base + ax0 >= vs || base + ax1 >= vs) {
+                px[k] = 0.0f;
+                py[k] = 0.0f;
+            } else {
+                px[k] = v[base + ax0];
+                py[k] = v[base + ax1];
+            }
+        }
+        float e0x = px[1] - px[0], e0y = py[1] - py[0];
+        float e1x = px[2] - px[1], e1y = py[2] - py[1];
+        float cross = e0x * e1y - e0y * e1x;
+        float area = (px[0] * py[1] - py[0] * px[1]) * 0.5f;
+        if (cross * area < 0.0f) {  // reflex corner by the library's test
+            ++guess;
+            continue;
+        }
+        bool covered = false;
+        for (size_t o = 3; o < m; ++o) {
+            size_t base = 3 * (size_t)rest[(guess + o) % m];
+            if (base + ax0 >= vs || base + ax1 >= vs) continue;
+            if (obj_pnpoly3(px, py, v[base + ax0], v[base + ax1])) {
+                covered = true;
+                break;
+            }
+        }
+        if (covered) {
+            ++guess;
+            continue;
+        }
+        obj_emit(out, ind[0], ind[1], ind[2]);
+        rest.erase(rest.begin() + (long)((guess + 1) % m));
+    }
+    if (rest.size() == 3) obj_emit(out, rest[0], rest[1], rest[2]);
+}
+
+// One corner `i[/j][/k]`; counts = {vertices, normals, texcoords} read so far.  false = the file fails.
+static bool obj_corner(const char** tok, const int counts[3], int* v_out) {
+    auto fix = [](int raw, int n, bool zero_ok, int* out) {
+        if (raw > 0) {
+            *out = raw - 1;
+            return true;
+        }
+        if (raw == 0) {
+            *out = -1;
+            return zero_ok;
+        }
+        *out = n + raw;
+        return *out >= 0;
+    };
+    int dummy;
+    if (!fix(atoi(*tok), counts[0], false, v_out)) return false;
+    *tok += strcspn(*tok, "/ \t\r");
+    if (**tok != '/') return true;
+    ++*tok;
+    if (**tok == '/') {  // i//k
+        ++*tok;
+        if (!fix(atoi(*tok), counts[1], true, &dummy)) return false;
+        *tok += strcspn(*tok, "/ \t\r");
+        return true;
+    }
+    if (!fix(atoi(*tok), counts[2], true, &dummy)) return false;  // i/j
+    *tok += strcspn(*tok, "/ \t\r");
+    if (**tok != '/') return true;
+    ++*tok;  // i/j/k
+    if (!fix(atoi(*tok), counts[1], true, &dummy)) return false;
+    *tok += strcspn(*tok, "/ \t\r");
+    return true;
+}
+
 static bool load_obj(const std::string& path, std::vector<V3>& verts, std::vector<uint32_t>& tris, std::string& log) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) {
         log += "Failed to load OBJ: " + path + "\n";
         return false;
     }
-    std::string line;
-    std::vector<char> buf(1 << 16);
-    while (fgets(buf.data(), (int)buf.size(), f)) {
-        const char* t = buf.data();
+    std::string text;
+    {
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) text.append(chunk, got);
+        fclose(f);
+    }
+    std::vector<float> v;
+    std::vector<ObjFace> group;
+    std::vector<uint32_t> raw;
+    int counts[3] = {0, 0, 0};
+    auto flush = [&]() {
+        for (const ObjFace& fc : group) obj_triangulate(fc, v, raw);
+        group.clear();
+    };
+    auto is_sp = [](char c) { return c == ' ' || c == '\t'; };
+    bool ok = true;
+    size_t pos = 0;
+    while (ok && pos < text.size()) {
+        // line ends: \n, \r\n or a lone \r (h:767-799); trailing blanks are trimmed first (h:2094-2097)
+        size_t eol = text.find_first_of("\r\n", pos);
+        if (eol == std::string::npos) eol = text.size();
+        std::string line = text.substr(pos, eol - pos);
+        pos = eol + 1;
+        if (eol < text.size() && text[eol] == '\r' && pos < text.size() && text[pos] == '\n') ++pos;
+        size_t keep = line.find_last_not_of(" \t");
+        line.erase(keep == std::string::npos ? 0 : keep + 1);
+        const char* t = line.c_str();
         t += strspn(t, " \t");
-        if (t[0] == 'v' && (t[1] == ' ' || t[1] == '\t')) {
+        if (t[0] == 'v' && is_sp(t[1])) {
             t += 2;
             float x = tinyobj_parse_real(&t), y = tinyobj_parse_real(&t), z = tinyobj_parse_real(&t);
-            verts.push_back(v3(x, y, z));
-        } else if (t[0] == 'f' && (t[1] == ' ' || t[1] == '\t')) {
+            v.push_back(x);
+            v.push_back(y);
+            v.push_back(z);
+            counts[0]++;
+        } else if (t[0] == 'v' && t[1] == 'n' && is_sp(t[2])) {
+            counts[1]++;
+        } else if (t[0] == 'v' && t[1] == 't' && is_sp(t[2])) {
+            counts[2]++;
+        } else if ((t[0] == 'f' || t[0] == 'l' || t[0] == 'p') && is_sp(t[1])) {
+            const bool is_face = t[0] == 'f';
             t += 2;
-            std::vector<int> idx;
-            while (true) {
-                t += strspn(t, " \t");
-                if (*t == '\0' || *t == '\r' || *t == '\n') break;
-                int vi = atoi(t);
-                int n = (int)verts.size();
-                int fixed = vi > 0 ? vi - 1 : (vi < 0 ? n + vi : -1);  // tiny_obj_loader.h:819-850
-                idx.push_back(fixed);
-                t += strcspn(t, " \t\r\n");
-            }
-            for (size_t k = 2; k < idx.size(); ++k) {
-                int a = idx[0], b = idx[k - 1], c = idx[k];
-                size_t nv = verts.size();
-                if (a < 0 || b < 0 || c < 0 || (size_t)a >= nv || (size_t)b >= nv || (size_t)c >= nv) {
-                    log += "Invalid triangle indices\n";  // SceneLoader.cpp:62-66
-                    continue;
+            t += strspn(t, " \t");
+            ObjFace fc;
+            while (*t != '\0' && *t != '\r' && *t != '\n' && *t != '#') {
+                int vi = -1;
+                if (!obj_corner(&t, counts, &vi)) {
+                    ok = false;
+                    break;
                 }
-                tris.push_back((uint32_t)a);
-                tris.push_back((uint32_t)b);
-                tris.push_back((uint32_t)c);
+                fc.v.push_back(vi);
+                t += strspn(t, " \t\r");
             }
+            if (ok && is_face) group.push_back(std::move(fc));
+        } else if ((t[0] == 'g' || t[0] == 'o') && is_sp(t[1])) {  // h:2936,2990: a bare "g" does not match
+            flush();
         }
     }
-    fclose(f);
+    if (!ok) {
+        log += "Failed to load OBJ: " + path + "\n";
+        return false;
+    }
+    flush();
+    for (size_t i = 0; i + 2 < v.size(); i += 3) verts.push_back(v3(v[i], v[i + 1], v[i + 2]));
+    const size_t nv = verts.size();
+    for (size_t i = 0; i + 2 < raw.size(); i += 3) {
+        if (raw[i] >= nv || raw[i + 1] >= nv || raw[i + 2] >= nv) {
+            log += "Invalid triangle indices\n";  // SceneLoader.cpp:62-66
+            continue;
+        }
+        tris.push_back(raw[i]);
+        tris.push_back(raw[i + 1]);
+        tris.push_back(raw[i + 2]);
+    }
     return true;
 }
 

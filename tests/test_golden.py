@@ -88,3 +88,27 @@ def test_cornell_config0_cpu_plumbing():
     left, right = img[100:180, 20:50, :3].mean((0, 1)), img[100:180, 206:236, :3].mean((0, 1))
     assert left[0] > 2 * left[1] and right[1] > 2 * right[0]      # red wall / green wall
     assert ct["emissive_hits"] > 0 and ct["misses"] > 0
+
+
+def test_polygon_soup_ingest(tmp_path):
+    """OBJ polygons: product loader and oracle against what the reference's tinyobjloader 2.0.0 returns for the
+    committed input (fixture made by tests/golden/make_ingest_golden.py with the real library)."""
+    import ctypes as C
+    from metalpathtracer_amd import host
+    exp = np.load(os.path.join(GOLDEN, "polygon_soup_expected.npz"))
+    verts, tris = exp["verts"], exp["tris"]
+    want = np.stack([verts[tris[:, k]] for k in range(3)], 1)   # position 0, scale 1: 0 + 1*v == v bit for bit
+    want = np.float32(0) + np.float32(1) * want
+    xml = tmp_path / "soup.xml"
+    xml.write_text('<Scene><Mesh file="%s" position="0,0,0" scale="1" albedo="1,1,1" emission="0,0,0"/></Scene>'
+                   % os.path.join(GOLDEN, "polygon_soup.obj"))
+    hs = host.Scene()
+    st, _ = host.SceneLoader.LoadSceneFromXML(str(xml), hs)
+    assert st == 0
+    osn = ob.OracleScene()
+    assert osn.load_xml(str(xml)) == 0
+    op = np.zeros((osn.prim_count, 3, 4), np.float32)
+    ob.lib().orc_scene_pack_prims(osn.h, op.ctypes.data_as(C.POINTER(C.c_float)))
+    for got in (hs.buffers()[1], op):
+        assert got.shape[0] == len(tris)
+        np.testing.assert_array_equal(got[:, :, :3].view(np.uint32), want.view(np.uint32))
