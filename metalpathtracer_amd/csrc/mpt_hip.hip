@@ -75,7 +75,7 @@ struct mpt_ctx {
     bool time_kernels = true;
     WaveRings ring = {};       // wave-local wavefront: private light + heavy rings, MPT_WL_RING records each
     size_t ring_waves = 0;
-    WaveBudgets budgets = {{8, 24, 72, 0x7FFFFFFF, 0}};  // box-test loop trips per step of ring 0..3 (measured best
+    WaveBudgets budgets = {{8, 24, 72, 0x7FFFFFFF, 0x7FFFFFFF}};  // box-test loop trips per step of ring 0..3 (measured best
                                                         // ladder; an unlimited ring-3 budget leaves ring 4 unused)
     uint32_t wl_min = 64, wl_div = 16;  // guided path-id claims: max(wl_min, remaining / (wl_div * waves))
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
@@ -785,7 +785,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
                 HIPCHK(hipMalloc(&r.dt, n * 16));
                 HIPCHK(hipMalloc(&r.tl, n * 16));
                 HIPCHK(hipMalloc(&r.ia, n * 16));
-                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 24));  // + room for the MPT_DEBUG_WAVE_TIMES records
+                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 64));  // + room for the MPT_DEBUG_WAVE_TIMES records
                 ctx->ring_waves = waves;
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
@@ -1049,6 +1049,6 @@ extern "C" void mpt_debug_bind(mpt_ctx* ctx) { g_dbg_ctx = ctx; }
 extern "C" int mpt_debug_wave_times(unsigned long long* out, int n) {
     mpt_ctx* ctx = g_dbg_ctx;
     const size_t off = ctx->ring_waves * MPT_WL_LEVELS * MPT_WL_RING;
-    return (int)hipMemcpy(out, (const char*)ctx->ring.tv + off * 16, (size_t)n * 24, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out, (const char*)ctx->ring.tv + off * 16, (size_t)n * 64, hipMemcpyDeviceToHost);
 }
 #endif

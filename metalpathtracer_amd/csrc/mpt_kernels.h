@@ -423,6 +423,7 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 #define MPT_WL_LEVELS 5u
 #define MPT_WL_RING 512u       // records per ring
 #define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
+#define MPT_WL_NO_BUDGET 0x7FFFFFFFu  // budgets at or above this mean "run to completion"
 struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING]
     float4* od;                // (o.xyz, d.x)
     float4* dt;                // (d.y, d.z, thr.r, thr.g)
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
     WorkCount wc = {0, 0, 0, 0, 0, 0};
 #ifdef MPT_DEBUG_WAVE_TIMES
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long t_exh = 0ull;
+    unsigned long long t_exh = 0ull, t_claim = 0ull, dbg_steps = 0ull, dbg_left = 0ull, dbg_blk = 0ull;
 #endif
     for (;;) {
         // ---- step choice: deepest ring with a full wave of rays; else new paths; else drain ----------------------
@@ -487,6 +488,9 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                         const uint32_t left = seen < re ? re - seen : 0u;
                         blk = (left / (wl_div * waves_per_group)) & ~63u;
                         blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
+                        // a range entered by stealing is near its end but `seen` knows nothing about it yet: the first
+                        // claim there is the minimum (it returns the cursor, which sizes the following ones)
+                        if (t > 0u) blk = wl_min;
                         k = atomicAdd(&pp.ctr[MPT_CTR_CURSOR(grp)], blk);
                         if (k < re) {
                             got = true;
@@ -503,6 +507,16 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                 rend = __builtin_amdgcn_readfirstlane(rend);
                 grp = __builtin_amdgcn_readfirstlane(grp);
                 seen = k;
+#ifdef MPT_DEBUG_WAVE_TIMES
+                if (got) {
+                    t_claim = __builtin_amdgcn_s_memrealtime();
+                    dbg_steps = 0ull;
+                    dbg_blk = blk;
+                } else {
+                    t_exh = __builtin_amdgcn_s_memrealtime();
+                    for (uint32_t q = 0; q < MPT_WL_LEVELS; ++q) dbg_left |= (unsigned long long)cnt[q] << (12u * q);
+                }
+#endif
                 if (!got) {
                     exhausted = true;
                 } else {
@@ -512,8 +526,12 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
             }
             if (exhausted) {
                 // Drain: no new paths and no ring holds a full wave.  What is left in ALL rings is merged into
-                // full-width steps without a budget (deepest ring first), instead of one partial step per ring and
-                // bounce generation: with per-ring partial steps every wave spent 1.4-2.2 ms draining.
+                // full-width steps without a budget (deepest ring first).  Measured alternatives: one partial step per
+                // ring and bounce generation (1.4-2.2 ms per wave instead of 0.5-0.9), merged steps that keep the
+                // largest finite budget and park heavy rays in the unbudgeted ring (3 % slower at 32 spp, equal at
+                // 256), staggered retirement of the waves of a workgroup (no gain).  The drain is bound by the
+                // latency of the heaviest rays (~1000 box tests, ~100 us each even on an idle SIMD) times the bounce
+                // chain, not by the number of rays left.
                 uint32_t total = 0;
 #pragma unroll
                 for (int k = 0; k < (int)MPT_WL_LEVELS; ++k) total += cnt[k];
@@ -521,6 +539,9 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                 level = (int)MPT_WL_LEVELS;  // merged drain step
             }
         }
+#ifdef MPT_DEBUG_WAVE_TIMES
+        if (!exhausted) dbg_steps += 1ull << (12u * (uint32_t)(level + 1));  // field 0 = primary steps
+#endif
         PathState ps;
         PathRngDev g;
         bool valid = false;
@@ -586,7 +607,9 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                 valid = true;
             }
         }
-        const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS - 1;
+        // the last ring never has a budget; a ring whose budget is "none" runs the plain (unsynchronised) loop
+        const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS - 1 && budget < MPT_WL_NO_BUDGET;
+        const int park_ring = level + 1;  // where unfinished queries go
         bool alive = false, parked = false;
         if (valid) {
             bool done;
@@ -620,12 +643,12 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
             uint32_t h = 0, c = 0;
 #pragma unroll
             for (int k = 1; k < (int)MPT_WL_LEVELS; ++k)
-                if (k == level + 1) {
+                if (k == park_ring) {
                     h = head[k];
                     c = cnt[k];
                 }
             if (parked) {
-                const uint32_t at = wbase + (uint32_t)(level + 1) * MPT_WL_RING + ((h + c + wave_rank(pm)) & M);
+                const uint32_t at = wbase + (uint32_t)park_ring * MPT_WL_RING + ((h + c + wave_rank(pm)) & M);
                 ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
                 ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
                 ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
@@ -634,22 +657,23 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
             }
 #pragma unroll
             for (int k = 1; k < (int)MPT_WL_LEVELS; ++k)
-                if (k == level + 1) cnt[k] = c + (uint32_t)__popcll(pm);
+                if (k == park_ring) cnt[k] = c + (uint32_t)__popcll(pm);
         }
         uint32_t worst = 0;
 #pragma unroll
         for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) worst = cnt[k] > worst ? cnt[k] : worst;
         if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (see capacity note above)
-#ifdef MPT_DEBUG_WAVE_TIMES
-        if (exhausted && t_exh == 0ull) t_exh = __builtin_amdgcn_s_memrealtime();
-#endif
     }
 #ifdef MPT_DEBUG_WAVE_TIMES  // diagnostics build: per-wave (start, cursor exhausted, end) timestamps, 100 MHz ticks
     if (lane == 0) {
         unsigned long long* dbg = (unsigned long long*)(ring.tv + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING);
-        dbg[3 * wave_id] = t_start;
-        dbg[3 * wave_id + 1] = t_exh;
-        dbg[3 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();
+        dbg[8 * wave_id] = t_start;
+        dbg[8 * wave_id + 1] = t_exh;
+        dbg[8 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();
+        dbg[8 * wave_id + 3] = t_claim;
+        dbg[8 * wave_id + 4] = dbg_steps;
+        dbg[8 * wave_id + 5] = dbg_left;
+        dbg[8 * wave_id + 6] = dbg_blk;
     }
 #endif
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);

@@ -15,7 +15,7 @@ for rep in range(2):
     ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2)
 st = ctx.stats()
 n = 8192
-buf = np.zeros((n, 3), np.uint64)
+buf = np.zeros((n, 8), np.uint64)
 L.mpt_debug_wave_times(buf.ctypes.data_as(C.c_void_p), n)
 t0 = buf[:, 0].min()
 start = (buf[:, 0] - t0).astype(np.float64) / 100.0
@@ -27,3 +27,14 @@ print("wave start (us):      ", pc(start))
 print("cursor exhausted (us):", pc(exh))
 print("wave end (us):        ", pc(end))
 print("drain per wave (us):  ", pc(end - exh))
+
+claim = (buf[:, 3] - t0).astype(np.float64) / 100.0
+print("last claim (us):      ", pc(claim))
+print("exhaust - last claim: ", pc(exh - claim))
+late = np.argsort(exh)[-int(n * 0.02):]
+early = np.argsort(exh)[:int(n * 0.5)]
+def unpack(a): return np.stack([(a >> np.uint64(12 * k)) & np.uint64(0xFFF) for k in range(6)], 1).astype(np.int64)
+for name, sel in (("latest 2%", late), ("earliest 50%", early)):
+    st_ = unpack(buf[sel, 4]); lf = unpack(buf[sel, 5])[:, :5]
+    print(name, "steps after last claim [prim,L0..L4] mean", st_.mean(0).round(1), "left at exhaust [L0..L4] mean", lf.mean(0).round(1),
+          "last blk mean %.0f" % buf[sel, 6].astype(np.float64).mean(), "exh-claim mean %.0f us" % (exh[sel] - claim[sel]).mean(), "drain mean %.0f" % (end[sel] - exh[sel]).mean())
