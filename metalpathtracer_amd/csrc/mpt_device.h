@@ -233,8 +233,14 @@ template <bool COUNT, bool ALL_LDS, bool BUDGETED>
 __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d, uint32_t& node,
                                                    float& best_t, int& best_prim, uint32_t budget, WorkCount& wc) {
     const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;  // PathTracing.h:61 (per call there)
-    uint32_t i = node;
     const uint32_t n_nodes = sc.n_nodes, n_lds = sc.n_lds_nodes;
+    // A direction with a NaN component (normalize of a zero vector: e.g. a refraction at the critical angle whose
+    // discriminant rounds below zero) hits nothing — every sphere / triangle test mixes all three components and ends
+    // in a comparison with NaN, which is false — but its slab tests PASS every box (min / max drop the NaN operand), so
+    // the reference walks the whole tree: 0.5 s for one such ray on a 1 M-triangle scene, with every other wave of
+    // the launch waiting for it.  The result of that walk is "miss"; return it without walking.  (The work counters
+    // then lack this walk; the oracle, which restates the reference, makes it.)
+    uint32_t i = (d.x != d.x || d.y != d.y || d.z != d.z) ? n_nodes : node;
     uint32_t trips = 0;  // trips of the box-test loop this wave has made (kept equal in all lanes, see below)
     for (;;) {
         uint32_t leaf_first = 0, leaf_count = 0;

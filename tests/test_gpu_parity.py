@@ -67,10 +67,15 @@ def test_closest_hit_matches_oracle_bitwise(gpu_ctx):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     # edge cases: axis-parallel directions (1/0 = inf in the slab test), rays from inside the light sphere,
     # rays grazing the big sphere, un-normalised and zero directions
+    # ... and directions with NaN / Inf components (normalize of a zero vector happens at the critical angle of a
+    # refraction): the reference walks the whole tree for them and hits nothing, the device returns that miss directly
+    nan, inf = np.nan, np.inf
     extra_o = np.array([[0, 20, 50], [0, 20, 50], [0, 20, 50], [0, 20, 0], [0, 20, 0], [40, 100, 50], [-25, 5, 50],
-                        [0, 20, 50], [0, 20, 50]], np.float32)
+                        [0, 20, 50], [0, 20, 50], [0, 20, 50], [0, 20, 50], [0, 20, 50], [0, 20, 50], [0, 20, 50],
+                        [-25, 5, 50]], np.float32)
     extra_d = np.array([[0, 0, -1], [0, -1, 0], [1, 0, 0], [0, 0, 1], [0, 1, 0], [0, 0, -1], [0, 0, -1],
-                        [0, 0, -7.5], [0, 0, 0]], np.float32)
+                        [0, 0, -7.5], [0, 0, 0], [nan, nan, nan], [nan, 0.5, -0.5], [0, nan, -1], [inf, 0, 0],
+                        [0, -inf, -1], [nan, nan, -1]], np.float32)
     o = np.concatenate([o, extra_o])
     d = np.concatenate([d, extra_d])
     t, prim, nrm, front = gpu_ctx.trace_rays(o, d)
