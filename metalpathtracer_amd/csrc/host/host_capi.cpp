@@ -33,12 +33,30 @@ static void copy_text(const std::string& s, char* dst, size_t cap) {
 
 extern "C" {
 
+// The scene entry points allocate (std::vector growth, new[]): no exception may cross the C ABI (include/mpt_host.h).
+#define SCENE_GUARD(fail_value, ...)  \
+    try {                             \
+        __VA_ARGS__                   \
+    } catch (...) {                   \
+        return fail_value;            \
+    }
+
 int mpt_scene_create(mpt_scene** out) {
     if (!out) return MPT_ERR_INVALID_ARG;
-    *out = new mpt_scene();
-    (*out)->sc = new Scene();
-    (*out)->owned = true;
-    return MPT_OK;
+    *out = nullptr;
+    SCENE_GUARD(MPT_ERR_HIP, {
+        mpt_scene* h = new mpt_scene();
+        h->sc = nullptr;
+        h->owned = true;
+        try {
+            h->sc = new Scene();
+        } catch (...) {
+            delete h;
+            throw;
+        }
+        *out = h;
+        return MPT_OK;
+    })
 }
 int mpt_scene_destroy(mpt_scene* s) {
     if (!s || !s->owned) return MPT_ERR_INVALID_ARG;
@@ -48,15 +66,19 @@ int mpt_scene_destroy(mpt_scene* s) {
 }
 int mpt_scene_clear(mpt_scene* s) {
     if (!s) return MPT_ERR_INVALID_ARG;
-    s->sc->clear();
-    return MPT_OK;
+    SCENE_GUARD(MPT_ERR_HIP, {
+        s->sc->clear();
+        return MPT_OK;
+    })
 }
 int mpt_scene_load_xml(mpt_scene* s, const char* xml_path, const char* asset_root, char* log, size_t log_cap) {
     if (!s || !xml_path) return -1;
-    std::string text;
-    int st = SceneLoader::Load(xml_path, s->sc, asset_root ? asset_root : "", &text);
-    copy_text(text, log, log_cap);
-    return st;
+    SCENE_GUARD(-1, {
+        std::string text;
+        int st = SceneLoader::Load(xml_path, s->sc, asset_root ? asset_root : "", &text);
+        copy_text(text, log, log_cap);
+        return st;
+    })
 }
 int mpt_scene_add_primitive(mpt_scene* s, int type, const float d0[3], const float d1[3], const float d2[3],
                             const float mat[8]) {
@@ -70,13 +92,17 @@ int mpt_scene_add_primitive(mpt_scene* s, int type, const float d0[3], const flo
     p.material.materialType = mat[3];
     p.material.emissionColor = mpt::float3(mat[4], mat[5], mat[6]);
     p.material.emissionPower = mat[7];
-    s->sc->addPrimitive(p);
-    return MPT_OK;
+    SCENE_GUARD(MPT_ERR_HIP, {
+        s->sc->addPrimitive(p);
+        return MPT_OK;
+    })
 }
 int mpt_scene_build_bvh(mpt_scene* s, int mode) {
     if (!s || (mode != 0 && mode != 1)) return MPT_ERR_INVALID_ARG;
-    s->sc->buildBVH(mode == 0 ? Scene::BuildMode::ReferenceSweep : Scene::BuildMode::BinnedCentroid);
-    return MPT_OK;
+    SCENE_GUARD(MPT_ERR_HIP, {
+        s->sc->buildBVH(mode == 0 ? Scene::BuildMode::ReferenceSweep : Scene::BuildMode::BinnedCentroid);
+        return MPT_OK;
+    })
 }
 int mpt_scene_counts(const mpt_scene* s, uint64_t* prims, uint64_t* triangles, uint64_t* nodes, int32_t* depth) {
     if (!s) return MPT_ERR_INVALID_ARG;
@@ -91,6 +117,7 @@ int mpt_scene_copy_buffers(const mpt_scene* s, float* bvh, float* prims, float* 
     if (!s) return MPT_ERR_INVALID_ARG;
     const Scene& sc = *s->sc;
     const size_t P = sc.getPrimitiveCount(), N = sc.getBVHNodeCount();
+    SCENE_GUARD(MPT_ERR_HIP, {
     if (bvh) {
         mpt::float4* b = sc.createBVHBuffer();
         std::memcpy(bvh, b, N * 32);
@@ -112,6 +139,7 @@ int mpt_scene_copy_buffers(const mpt_scene* s, float* bvh, float* prims, float* 
         delete[] b;
     }
     return MPT_OK;
+    })
 }
 
 int mpt_camera_reset_values(float pos[3], float fwd[3], float up[3], float* vfov_deg) {

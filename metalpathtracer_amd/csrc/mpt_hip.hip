@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <map>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -130,7 +131,7 @@ extern "C" const char* mpt_status_string(int s) {
 }
 extern "C" const char* mpt_last_error(const mpt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
+static int create_impl(int device_ordinal, mpt_ctx** out) {
     if (!out) return MPT_ERR_INVALID_ARG;
     *out = nullptr;
     int n = 0;
@@ -248,7 +249,7 @@ static inline float int_to_bits(int i) {
 }
 }  // namespace
 
-extern "C" int mpt_upload_scene(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims,
+static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims,
                                 const float* mats, const int32_t* prim_idx, uint64_t n_prims) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
     if (!bvh || !prims || !mats || !prim_idx || n_nodes == 0 || n_prims == 0)
@@ -471,14 +472,14 @@ extern "C" int mpt_upload_scene(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes
     return MPT_OK;
 }
 
-extern "C" int mpt_set_uniforms(mpt_ctx* ctx, const mpt_uniforms* u) {
+static int set_uniforms_impl(mpt_ctx* ctx, const mpt_uniforms* u) {
     if (!ctx || !u) return MPT_ERR_INVALID_ARG;
     ctx->u = *u;
     ctx->have_uniforms = true;
     return MPT_OK;
 }
 
-extern "C" int mpt_resize(mpt_ctx* ctx, uint32_t width, uint32_t height) {
+static int resize_impl(mpt_ctx* ctx, uint32_t width, uint32_t height) {
     if (!ctx || width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 31))
         return fail(ctx, MPT_ERR_INVALID_ARG, "bad size");
     HIPCHK(hipSetDevice(ctx->device));
@@ -515,7 +516,7 @@ extern "C" int mpt_set_sum_buffer(mpt_ctx* ctx, void* p) {
     ctx->d_sum = p ? (float4*)p : ctx->d_sum_own;
     return MPT_OK;
 }
-extern "C" int mpt_clear_sum(mpt_ctx* ctx) {
+static int clear_sum_impl(mpt_ctx* ctx) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
     if (!ctx->d_sum) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
     HIPCHK(hipSetDevice(ctx->device));
@@ -529,7 +530,7 @@ extern "C" int mpt_synchronize(mpt_ctx* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MPT_OK;
 }
-extern "C" int mpt_read_frame(mpt_ctx* ctx, float* out) {
+static int read_frame_impl(mpt_ctx* ctx, float* out) {
     if (!ctx || !out) return MPT_ERR_INVALID_ARG;
     if (!ctx->d_accum[0]) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
     HIPCHK(hipSetDevice(ctx->device));
@@ -537,7 +538,7 @@ extern "C" int mpt_read_frame(mpt_ctx* ctx, float* out) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MPT_OK;
 }
-extern "C" int mpt_read_sum(mpt_ctx* ctx, float* out) {
+static int read_sum_impl(mpt_ctx* ctx, float* out) {
     if (!ctx || !out) return MPT_ERR_INVALID_ARG;
     if (!ctx->d_sum) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
     HIPCHK(hipSetDevice(ctx->device));
@@ -897,7 +898,7 @@ static int collect_pass_stats(mpt_ctx* ctx) {
     return MPT_OK;
 }
 
-extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
+static int render_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     int rc = check_ready(ctx, p);
     if (rc) return rc;
     HIPCHK(hipSetDevice(ctx->device));
@@ -940,7 +941,7 @@ extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
     return MPT_OK;
 }
 
-extern "C" int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p) {
+static int draw_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     int rc = check_ready(ctx, p);
     if (rc) return rc;
     HIPCHK(hipSetDevice(ctx->device));
@@ -961,7 +962,7 @@ extern "C" int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p) {
 }
 
 // ---- unit-test entry points -----------------------------------------------------------------------------------
-extern "C" int mpt_trace_rays(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out,
+static int trace_rays_impl(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out,
                               int32_t* prim_out, float* normal_out, int32_t* front_out) {
     if (!ctx || !o || !d || !t_out || !prim_out || !normal_out || !front_out || n == 0 || n > (1ull << 30))
         return fail(ctx, MPT_ERR_INVALID_ARG, "bad argument");
@@ -1009,7 +1010,7 @@ static int kat_run(mpt_ctx* ctx, const void* const* in, const size_t* in_bytes, 
     return MPT_OK;
 }
 
-extern "C" int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* h, float* f) {
+static int kat_pcg_impl(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* h, float* f) {
     if (!ctx || !seeds || !h || !f || n == 0 || n > (1u << 28)) return MPT_ERR_INVALID_ARG;
     const void* in[] = {seeds};
     size_t ib[] = {n * 4};
@@ -1020,7 +1021,7 @@ extern "C" int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint
                            (const uint32_t*)di[0], (uint32_t)n, (uint32_t*)dout[0], (float*)dout[1]);
     });
 }
-extern "C" int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* c, const uint32_t* k, uint64_t n, uint32_t* o) {
+static int kat_philox_impl(mpt_ctx* ctx, const uint32_t* c, const uint32_t* k, uint64_t n, uint32_t* o) {
     if (!ctx || !c || !k || !o || n == 0 || n > (1u << 26)) return MPT_ERR_INVALID_ARG;
     const void* in[] = {c, k};
     size_t ib[] = {n * 16, n * 8};
@@ -1031,7 +1032,7 @@ extern "C" int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* c, const uint32_t* k
                            (const uint32_t*)di[0], (const uint32_t*)di[1], (uint32_t)n, (uint32_t*)dout[0]);
     });
 }
-extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s, float* c) {
+static int kat_sincos_impl(mpt_ctx* ctx, const float* u, uint64_t n, float* s, float* c) {
     if (!ctx || !u || !s || !c || n == 0 || n > (1u << 28)) return MPT_ERR_INVALID_ARG;
     const void* in[] = {u};
     size_t ib[] = {n * 4};
@@ -1041,6 +1042,77 @@ extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s
         hipLaunchKernelGGL(k_kat_sincos, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const float*)di[0], (uint32_t)n, (float*)dout[0], (float*)dout[1]);
     });
+}
+
+
+// ---- exception barrier: nothing thrown by the host-side containers may cross the C ABI (include/mpt.h) --------
+template <class F>
+static int guarded(mpt_ctx* ctx, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        if (ctx) {
+            try {
+                ctx->err = std::string("host exception: ") + e.what();
+            } catch (...) {
+            }
+        }
+        return MPT_ERR_HIP;
+    } catch (...) {
+        return MPT_ERR_HIP;
+    }
+}
+
+extern "C" int mpt_create(int device_ordinal, mpt_ctx** out) {
+    return guarded(nullptr, [&] { return create_impl(device_ordinal, out); });
+}
+
+extern "C" int mpt_upload_scene(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims, const float* mats, const int32_t* prim_idx, uint64_t n_prims) {
+    return guarded(ctx, [&] { return upload_scene_impl(ctx, bvh, n_nodes, prims, mats, prim_idx, n_prims); });
+}
+
+extern "C" int mpt_set_uniforms(mpt_ctx* ctx, const mpt_uniforms* u) {
+    return guarded(ctx, [&] { return set_uniforms_impl(ctx, u); });
+}
+
+extern "C" int mpt_resize(mpt_ctx* ctx, uint32_t width, uint32_t height) {
+    return guarded(ctx, [&] { return resize_impl(ctx, width, height); });
+}
+
+extern "C" int mpt_clear_sum(mpt_ctx* ctx) {
+    return guarded(ctx, [&] { return clear_sum_impl(ctx); });
+}
+
+extern "C" int mpt_read_frame(mpt_ctx* ctx, float* out) {
+    return guarded(ctx, [&] { return read_frame_impl(ctx, out); });
+}
+
+extern "C" int mpt_read_sum(mpt_ctx* ctx, float* out) {
+    return guarded(ctx, [&] { return read_sum_impl(ctx, out); });
+}
+
+extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
+    return guarded(ctx, [&] { return render_impl(ctx, p); });
+}
+
+extern "C" int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p) {
+    return guarded(ctx, [&] { return draw_impl(ctx, p); });
+}
+
+extern "C" int mpt_trace_rays(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out, int32_t* prim_out, float* normal_out, int32_t* front_out) {
+    return guarded(ctx, [&] { return trace_rays_impl(ctx, o, d, n, t_out, prim_out, normal_out, front_out); });
+}
+
+extern "C" int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* h, float* f) {
+    return guarded(ctx, [&] { return kat_pcg_impl(ctx, seeds, n, h, f); });
+}
+
+extern "C" int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* c, const uint32_t* k, uint64_t n, uint32_t* o) {
+    return guarded(ctx, [&] { return kat_philox_impl(ctx, c, k, n, o); });
+}
+
+extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s, float* c) {
+    return guarded(ctx, [&] { return kat_sincos_impl(ctx, u, n, s, c); });
 }
 
 #ifdef MPT_DEBUG_WAVE_TIMES
