@@ -1,6 +1,6 @@
 import csv, glob, collections, sys
 for d in sys.argv[1:]:
-    fs = glob.glob('%s/*/*_counter_collection.csv' % d)
+    fs = glob.glob("%s/*/*_counter_collection.csv" % d) + glob.glob("%s/*_counter_collection.csv" % d)
     if not fs: print(d, "no csv"); continue
     rows = list(csv.DictReader(open(fs[0])))
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
