@@ -574,10 +574,16 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_wavelocal(PassParams pp
                 if (lane >= assigned && lane < assigned + tk) {
                     take = true;
                     my_ring = (uint32_t)k;
+#ifdef MPT_WL_FIFO
                     my_off = (head[k] + (lane - assigned)) & M;
+#else
+                    my_off = cnt[k] - tk + (lane - assigned);  // newest records first: they are still in L2
+#endif
                 }
                 if (level == k) budget = budgets.b[k];
+#ifdef MPT_WL_FIFO
                 head[k] = (head[k] + tk) & M;
+#endif
                 cnt[k] -= tk;
                 assigned += tk;
             }
