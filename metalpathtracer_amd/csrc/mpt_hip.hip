@@ -66,7 +66,7 @@ struct mpt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
     // launch geometry
-    int wg_size = 1024;
+    int wg_size = 0;                // 0 = the kernel's own choice (MPT_WG_SIZE overrides, clamped to the kernel's bound)
     const void* occ_fun = nullptr;  // cached occupancy query
     size_t occ_lds = 0;
     int occ_per_cu = 0;
@@ -175,7 +175,7 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_WL_MIN")) && atoi(e) >= 64) ctx->wl_min = (uint32_t)atoi(e) & ~63u;
     if ((e = getenv("MPT_TILE_ORDER"))) ctx->tile_order_mode = atoi(e);
     if ((e = getenv("MPT_WL_DIV")) && atoi(e) >= 1) ctx->wl_div = (uint32_t)atoi(e);
-    if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 1024;
+    if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 0;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
     for (int c = 0; c < 2; ++c)
@@ -747,10 +747,14 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
     const void* kfun = p->pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
                        : p->pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
                                                           : step_kernel(count_flag(p), all_lds);
+    // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel when the whole BVH is in
+    // LDS, 1024 otherwise)
+    const int wg_max = p->pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : 1024;
+    const int wg = ctx->wg_size > 0 && ctx->wg_size <= wg_max ? ctx->wg_size : wg_max;
     if (ctx->occ_fun == kfun && ctx->occ_lds == lds) {
         per_cu = ctx->occ_per_cu;
     } else {
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfun, ctx->wg_size, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfun, wg, lds));
         ctx->occ_fun = kfun;
         ctx->occ_lds = lds;
         ctx->occ_per_cu = per_cu;
@@ -775,7 +779,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
             HIPCHK(hipEventRecord(e0, st));
         }
         if (p->pipeline == MPT_PIPE_WAVELOCAL) {
-            const size_t waves = (size_t)grid * (ctx->wg_size / 64);
+            const size_t waves = (size_t)grid * (wg / 64);
             if (waves > ctx->ring_waves) {
                 WaveRings& r = ctx->ring;
                 hipFree(r.od); hipFree(r.dt); hipFree(r.tl); hipFree(r.ia); hipFree(r.tv);
@@ -791,10 +795,10 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
             void* args[] = {(void*)&pp, (void*)&ctx->ring, (void*)&ctx->budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
-            HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
+            HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
         } else {
             void* args[] = {(void*)&pp};
-            HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
+            HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
         }
         if (time_kernels) {
             HIPCHK(hipEventRecord(e1, st));
@@ -835,7 +839,7 @@ static int run_pass(mpt_ctx* ctx, const mpt_render_params* p, uint32_t sample_be
             }
             {
                 void* args[] = {(void*)&pp, (void*)&parity};
-                HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(ctx->wg_size), args, lds, st));
+                HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
             }
             if (time_kernels) {
                 HIPCHK(hipEventRecord(e1, st));

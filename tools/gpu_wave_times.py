@@ -14,7 +14,7 @@ for rep in range(2):
     ctx.clear_sum(); ctx.reset_stats()
     ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2)
 st = ctx.stats()
-n = 8192
+n = int(os.environ.get("WAVES", "6144"))
 buf = np.zeros((n, 8), np.uint64)
 L.mpt_debug_wave_times(buf.ctypes.data_as(C.c_void_p), n)
 t0 = buf[:, 0].min()
