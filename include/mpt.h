@@ -127,6 +127,16 @@ int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p);
  * (PathTracing.h:258) into the HDR sum buffer.  Synchronous; fills the timing fields of mpt_stats.  */
 int mpt_render(mpt_ctx* ctx, const mpt_render_params* p);
 
+/* The same, without waiting: enqueues the render and returns.  Up to two renders are in flight (a third call first
+ * collects the oldest); their trace kernels overlap on the device — the next render fills the compute units that the
+ * previous one's tail and resolve leave idle — while the updates of the HDR sum stay in submission order, so the
+ * result is bit-identical to consecutive mpt_render calls.  mpt_wait collects everything in flight; statistics of
+ * asynchronous renders appear in mpt_get_stats after they were collected (trace_kernel_ms / total_ms / trace_launches
+ * then accumulate until mpt_reset_stats or the next mpt_render).  Every other call that touches the scene, the size or
+ * the sum buffer waits by itself.  This mirrors Metal's commit() without waitUntilCompleted (Renderer.cpp:308).      */
+int mpt_render_async(mpt_ctx* ctx, const mpt_render_params* p);
+int mpt_wait(mpt_ctx* ctx);
+
 /* HDR sum buffer (RGBA32F, W*H*4 floats, row-major, top-left origin).  The pointer is device
  * memory on the context's device, e.g. for an RCCL reduce by the caller.  mpt_set_sum_buffer lets
  * the caller supply the storage (e.g. a torch tensor); pass NULL to return to the internal one.     */

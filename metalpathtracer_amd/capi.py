@@ -23,7 +23,7 @@ STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT
 # every symbol include/mpt.h declares (tests/test_capi_symbols.py checks header <-> library <-> this list)
 SYMBOLS = (
     "mpt_create", "mpt_destroy", "mpt_last_error", "mpt_status_string", "mpt_upload_scene", "mpt_set_uniforms",
-    "mpt_resize", "mpt_draw", "mpt_render", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
+    "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
     "mpt_read_frame", "mpt_read_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
     "mpt_trace_rays", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
 )
@@ -101,6 +101,8 @@ def load():
     L.mpt_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.mpt_draw.argtypes = [vp, C.POINTER(RenderParams)]
     L.mpt_render.argtypes = [vp, C.POINTER(RenderParams)]
+    L.mpt_render_async.argtypes = [vp, C.POINTER(RenderParams)]
+    L.mpt_wait.argtypes = [vp]
     L.mpt_sum_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.mpt_set_sum_buffer.argtypes = [vp, vp]
     L.mpt_clear_sum.argtypes = [vp]
@@ -189,6 +191,14 @@ class Context:
     def render(self, **kw):
         p = self.params(**kw)
         self._chk(self.L.mpt_render(self.h, C.byref(p)), "mpt_render")
+
+    def render_async(self, **kw):
+        """Enqueue a render and return; up to two overlap on the device.  wait() collects them (and their stats)."""
+        p = self.params(**kw)
+        self._chk(self.L.mpt_render_async(self.h, C.byref(p)), "mpt_render_async")
+
+    def wait(self):
+        self._chk(self.L.mpt_wait(self.h), "mpt_wait")
 
     def clear_sum(self):
         self._chk(self.L.mpt_clear_sum(self.h), "mpt_clear_sum")
