@@ -118,8 +118,8 @@ int mpt_resize(mpt_ctx* ctx, uint32_t width, uint32_t height);
 
 /* One reference frame: swap targets, run the hot path for 1 sample/pixel with the current
  * uniforms (frameCount as given), write the running mean into the current target —
- * Renderer::draw, R/Renderer/Renderer.cpp:269-310 + Fragment.metal:8-72.  Asynchronous on the
- * context's stream like MTL commit(); mpt_read_* synchronise.                                        */
+ * Renderer::draw, R/Renderer/Renderer.cpp:269-310 + Fragment.metal:8-72.  Returns when the frame is complete
+ * (its statistics are folded into mpt_get_stats); mpt_render_async is the commit()-style call.        */
 int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p);
 
 /* Batch rendering (this project's extension of the same loop): adds, for every owned pixel, the
