@@ -1,0 +1,53 @@
+"""bench.py end to end on the GPU box: the contract line (metric / roofline / cpu_baseline objects) at N = 1 and the
+N = 2 launch path (`python -m torch.distributed.run`, one rank per process) on the single GPU of the test box.  The
+2-rank run uses gloo for the reduce (two RCCL ranks cannot share one device) and both ranks render on GPU 0; it must
+produce the same image mean as the 1-rank run because the tile shards partition the pixels."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+SMALL = ["--steps", "2", "--warmup", "1", "--spp-per-step", "8", "--width", "640", "--height", "360"]
+
+
+def last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_single_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-spp", "2"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Mrays/s" and d["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["launches"] == 2
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
+    assert d["config"]["paths"] == 640 * 360 * 8 * 2
+
+
+def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():
+    env = dict(os.environ, MPT_BENCH_BACKEND="gloo", MPT_BENCH_SHARE_GPU="1")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", *SMALL, "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b = last_json(one.stdout), last_json(two.stdout)
+    assert b["n_gpus"] == 2 and "reduce" in b["config"]["parallelism"]
+    assert a["config"]["paths"] == b["config"]["paths"] and a["config"]["rays"] == b["config"]["rays"]
+    assert a["config"]["image_mean_rgb"] == b["config"]["image_mean_rgb"]      # every pixel has exactly one owner
