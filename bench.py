@@ -90,9 +90,17 @@ def cpu_baseline(args, scene_buffers, prim_count, tri_count):
     n_node = ct["node_pops"] / ct["rays"]
     n_prim = ct["prim_tests"] / ct["rays"]
     h = ct["bounces"] / ct["rays"]
+    # one core as well: 1/16 of the sample, at least 1 spp
+    spp1 = max(1, spp // 16)
+    t0 = time.perf_counter()
+    _, c1 = ob.render(u, scene_buffers, rng_mode=ob.RNG_PHILOX, max_depth=args.depth, accumulate=1, sample_count=spp1,
+                      seed=(1, 0), threads=1)
+    dt1 = time.perf_counter() - t0
     return dict(value=ct["rays"] / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
                 sample="%dx%d, %d spp, depth %d, philox seed (1,0): %d rays in %.2f s on %d threads"
-                       % (args.width, args.height, spp, args.depth, ct["rays"], dt, cores)), (n_node, n_prim, h)
+                       % (args.width, args.height, spp, args.depth, ct["rays"], dt, cores),
+                single_core={"value": c1["rays"] / dt1 / 1e6, "unit": "Mrays/s",
+                             "sample": "%d spp: %d rays in %.2f s on 1 thread" % (spp1, c1["rays"], dt1)}), (n_node, n_prim, h)
 
 
 def main():
@@ -212,6 +220,7 @@ def main():
                 "pipeline": PIPE_NAMES[pipe],
                 "parallelism": "8x8-tile interleave over %d rank(s)%s" % (world, " + 1 RCCL reduce(sum) of the HDR framebuffer" if world > 1 else ""),
                 "paths": paths_total, "rays": rays_total, "rays_per_path": rays_total / max(1, paths_total),
+                "mpaths_per_s": paths_total / elapsed / 1e6,
                 "image_mean_rgb": mean,
             },
         }

@@ -1026,6 +1026,7 @@ static int render_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     ctx->stats.trace_kernel_ms = 0;   // the synchronous call reports its own timings
     ctx->stats.trace_launches = 0;
     ctx->stats.total_ms = 0;
+    ctx->next_lane = 0;  // nothing is in flight: serial renders stay on lane 0 (the second lane allocates only if used)
     if ((rc = render_async_impl(ctx, p))) return rc;
     return wait_impl(ctx);
 }
