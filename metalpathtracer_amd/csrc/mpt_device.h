@@ -140,7 +140,22 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 struct WorkCount {
     uint32_t node_visits, aabb_hits, prim_tests;   // per lane (== the oracle's counters when summed)
     uint32_t node_iters, prim_iters, outer_iters;  // per WAVE loop trips (lane 0 only): x64 = issued lane slots
+#ifdef MPT_DEBUG_WAVE_TIMES
+    unsigned long long t_box, t_leaf;              // diagnostics build: shader-clock cycles spent in the two loops
+#endif
 };
+#ifdef MPT_DEBUG_WAVE_TIMES
+#define MPT_TIC(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MPT_TOC(acc, var)                                          \
+    do {                                                           \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        (acc) += now_ - (var);                                     \
+        (var) = now_;                                              \
+    } while (0)
+#else
+#define MPT_TIC(var) do { } while (0)
+#define MPT_TOC(acc, var) do { } while (0)
+#endif
 
 // One primitive record (3 x 16 B).  Primitives are stored by leaf depth (shallow leaves first); the first
 // n_lds_prims of them are staged in LDS behind the node image.  On scene.xml 65 % of all primitive tests hit the three
@@ -242,6 +257,7 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
     // then lack this walk; the oracle, which restates the reference, makes it.)
     uint32_t i = (d.x != d.x || d.y != d.y || d.z != d.z) ? n_nodes : node;
     uint32_t trips = 0;  // trips of the box-test loop this wave has made (kept equal in all lanes, see below)
+    MPT_TIC(tic_);
     for (;;) {
         uint32_t leaf_first = 0, leaf_count = 0;
         while (i < n_nodes && (!BUDGETED || trips < budget)) {
@@ -289,10 +305,12 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
         }
         // a lane that left the loop early (leaf found / done) adopts the trips the rest of the wave made meanwhile
         if (BUDGETED) trips = wave_max_u32(trips);
+        MPT_TOC(wc.t_box, tic_);
         if (leaf_count != 0u) {
             if (COUNT && first_active_lane()) wc.outer_iters++;
             leaf_test<COUNT>(sc, lds_nodes, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
         }
+        MPT_TOC(wc.t_leaf, tic_);
         // the wave goes round again only while some lane still has nodes to visit and budget is left
         if (__ballot(i < n_nodes && (!BUDGETED || trips < budget)) == 0ull) break;
     }

@@ -828,7 +828,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
                 HIPCHK(hipMalloc(&r.dt, n * 16));
                 HIPCHK(hipMalloc(&r.tl, n * 16));
                 HIPCHK(hipMalloc(&r.ia, n * 16));
-                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 64));  // + room for the MPT_DEBUG_WAVE_TIMES records
+                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 128));  // + room for the MPT_DEBUG_WAVE_TIMES records
                 L.ring_waves = waves;
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
@@ -1219,6 +1219,6 @@ extern "C" int mpt_debug_wave_times(unsigned long long* out, int n) {
     mpt_ctx* ctx = g_dbg_ctx;
     const Lane& L = ctx->lane[0];
     const size_t off = L.ring_waves * MPT_WL_LEVELS * MPT_WL_RING;
-    return (int)hipMemcpy(out, (const char*)L.ring.tv + off * 16, (size_t)n * 64, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out, (const char*)L.ring.tv + off * 16, (size_t)n * 128, hipMemcpyDeviceToHost);
 }
 #endif

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_step(PassParams pp, uin
     const uint32_t total_paths = desc->total_paths;
     const uint32_t regen_base = desc->regen_base;
     uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
+    WorkCount wc = {};
 
     const uint32_t waves_per_group = (gridDim.x * (blockDim.x >> 6) + MPT_NGROUP - 1) / MPT_NGROUP;
     uint32_t item = 0, item_last = 0;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams p
     const uint32_t total_paths = pp.desc->total_paths;
     const uint32_t waves_per_block = blockDim.x >> 6;
     uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
+    WorkCount wc = {};
     for (uint32_t chunk = blockIdx.x * waves_per_block + (threadIdx.x >> 6); chunk * 64u < total_paths;
          chunk += gridDim.x * waves_per_block) {
         PathState ps;
@@ -467,12 +467,14 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
     uint32_t seen = 0;                                 // cursor value (virtual index) at this wave's previous claim
     bool exhausted = false;
     uint32_t n_rays = 0, n_paths = 0;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
+    WorkCount wc = {};
 #ifdef MPT_DEBUG_WAVE_TIMES
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_exh = 0ull, t_claim = 0ull, dbg_steps = 0ull, dbg_left = 0ull, dbg_blk = 0ull;
+    unsigned long long reg_select = 0, reg_fetch = 0, reg_trace = 0, reg_shade = 0, reg_push = 0;  // cycles per region
 #endif
     for (;;) {
+        MPT_TIC(tic_);
         // ---- step choice: deepest ring with a full wave of rays; else new paths; else drain ----------------------
         int level = -1;  // -1 = primary step
 #pragma unroll
@@ -552,6 +554,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
 #ifdef MPT_DEBUG_WAVE_TIMES
         if (!exhausted) dbg_steps += 1ull << (12u * (uint32_t)(level + 1));  // field 0 = primary steps
 #endif
+        MPT_TOC(reg_select, tic_);
         PathState ps;
         PathRngDev g;
         bool valid = false;
@@ -627,6 +630,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS - 1 && budget < MPT_WL_NO_BUDGET;
         const int park_ring = level + 1;  // where unfinished queries go
         bool alive = false, parked = false;
+        MPT_TOC(reg_fetch, tic_);
         if (valid) {
             bool done;
             if (budgeted)
@@ -636,6 +640,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 done = closest_hit_resume<COUNT, ALL_LDS, false>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
                                                                 0xFFFFFFFFu, wc);
             if (fresh) n_rays++;  // a resumed query was counted when it started
+            MPT_TOC(reg_trace, tic_);
             if (done) {
                 alive = shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, best_prim);
                 if (!alive)
@@ -644,6 +649,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 parked = true;
             }
         }
+        MPT_TOC(reg_shade, tic_);
         const unsigned long long am = __ballot(alive), pm = __ballot(parked);
         if (am != 0ull) {  // survivors are fresh rays -> ring 0
             if (alive) {
@@ -679,6 +685,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
 #pragma unroll
         for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) worst = cnt[k] > worst ? cnt[k] : worst;
         if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (see capacity note above)
+        MPT_TOC(reg_push, tic_);
     }
 #ifdef MPT_DEBUG_WAVE_TIMES  // diagnostics build: per-wave (start, cursor exhausted, end) timestamps, 100 MHz ticks
     if (lane == 0) {
@@ -690,6 +697,14 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         dbg[8 * wave_id + 4] = dbg_steps;
         dbg[8 * wave_id + 5] = dbg_left;
         dbg[8 * wave_id + 6] = dbg_blk;
+        unsigned long long* reg = dbg + 8ull * n_waves + 8ull * wave_id;
+        reg[0] = reg_select;
+        reg[1] = reg_fetch;
+        reg[2] = reg_trace;
+        reg[3] = reg_shade;
+        reg[4] = reg_push;
+        reg[5] = wc.t_box;
+        reg[6] = wc.t_leaf;
     }
 #endif
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(1024) void k_trace_rays(SceneDev sc, const float* o
     F3 ro = f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     float t;
     int prim;
-    WorkCount wc = {0, 0, 0, 0, 0, 0};
+    WorkCount wc = {};
     closest_hit<false, false>(sc, (LdsNodes)lds_nodes, ro, rd, t, prim, wc);
     t_out[i] = t;
     if (prim >= 0) {
