@@ -1,5 +1,6 @@
 // host_capi.cpp — extern "C" surface of the host layer (include/mpt_host.h).
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -134,9 +135,13 @@ int mpt_scene_copy_buffers(const mpt_scene* s, float* bvh, float* prims, float* 
         delete[] b;
     }
     if (prim_idx) {
+        // the index array exists only after buildBVH (R/Scene/Scene.h:157-167 sizes it by primitiveIndices); before
+        // that the caller's P entries are filled with the identity order the builder would start from
+        const size_t have = sc.getPrimitiveIndices().size();
         int* b = sc.createPrimitiveIndexBuffer();
-        std::memcpy(prim_idx, b, P * 4);
+        std::memcpy(prim_idx, b, std::min(have, P) * 4);
         delete[] b;
+        for (size_t i = have; i < P; ++i) prim_idx[i] = static_cast<int32_t>(i);
     }
     return MPT_OK;
     })

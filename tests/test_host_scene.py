@@ -149,3 +149,19 @@ def test_image_writers(tmp_path):
     assert host.write_ppm(str(tmp_path / "a.ppm"), img, gamma=1.0) == 0
     raw = (tmp_path / "a.ppm").read_bytes()
     assert raw.startswith(b"P6\n5 3\n255\n") and raw[len(b"P6\n5 3\n255\n"):][:3] == bytes([255, 128, 64])
+
+
+def test_buffers_before_build_bvh_are_well_defined():
+    """Scene::create*Buffer before buildBVH: no nodes, primitives in document order, identity index order (found by
+    running the CPU suite under AddressSanitizer: the index copy used to read past a zero-length array)."""
+    import numpy as np
+    from conftest import ASSETS
+    import os
+    from metalpathtracer_amd import host
+    sc = host.Scene()
+    st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ASSETS, "cornell.xml"), sc)
+    assert st == 0
+    bvh, prims, mats, idx = sc.buffers()
+    P = sc.getPrimitiveCount()
+    assert bvh.shape[0] == 0 and prims.shape[0] == P and mats.shape[0] == P
+    assert idx.tolist() == list(range(P))
