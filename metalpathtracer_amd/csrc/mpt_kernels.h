@@ -397,6 +397,26 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams p
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
 }
 
+// Result slots are written once and read once, much later, by the resolve kernel: streaming (non-temporal) accesses
+// keep them from evicting the ring records the trace kernel is about to pop.
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_slot(float4* slots, uint32_t path, float r, float g, float b, float a) {
+#ifdef MPT_SLOTS_TEMPORAL
+    slots[path] = make_float4(r, g, b, a);
+#else
+    v4f_nt v = {r, g, b, a};
+    __builtin_nontemporal_store(v, (v4f_nt*)(slots + path));
+#endif
+}
+__device__ __forceinline__ float4 load_slot(const float4* slots, uint32_t idx) {
+#ifdef MPT_SLOTS_TEMPORAL
+    return slots[idx];
+#else
+    v4f_nt v = __builtin_nontemporal_load((const v4f_nt*)(slots + idx));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+
 __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -644,7 +664,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             if (done) {
                 alive = shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, best_prim);
                 if (!alive)
-                    pp.slots[ps.path] = make_float4(clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+                    store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
             } else {
                 parked = true;
             }
@@ -719,7 +739,7 @@ __global__ void k_resolve_sum(PassParams pp, float4* sum, uint32_t n_local_tiles
     if (!path_to_pixel(pp, (tl * pp.S) * 64u + lane, px, py, s0)) return;
     float4 acc = sum[py * pp.width + px];
     for (uint32_t s = 0; s < pp.S; ++s) {
-        float4 v = pp.slots[(tl * pp.S + s) * 64u + lane];
+        float4 v = load_slot(pp.slots, (tl * pp.S + s) * 64u + lane);
         acc.x += v.x;
         acc.y += v.y;
         acc.z += v.z;
