@@ -31,6 +31,16 @@
 // render's trace kernel fills the CUs that the previous one's tail (and its resolve) leave idle (measured with two
 // contexts: +11 % at 1080p x 256 spp, +15 % for a 1/8 tile shard).  Resolves are chained in submission order, so the
 // HDR sum is bit-identical to the serial schedule.
+// Box-test trips granted per step of ring 0..LEVELS-2 (the last ring runs to completion).  Measured on scene.xml at
+// 1080p x 256 spp: 8/20/50/125 -> 29.3 ms, 8/24/72/inf -> 30.4, 8/16/32/64 -> 30.2, 8/16/32/inf -> 31.8, 8/12/24/48 -> 31.3:
+// bounce rays are heavy-tailed at every scale, so every ring needs a budget near the median of what its rays still need.
+static WaveBudgets default_budgets() {
+    WaveBudgets w;
+    const uint32_t ladder[] = {8, 20, 50, 125, 300, 700, 1600};
+    for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) w.b[k] = k + 1 < MPT_WL_LEVELS && k < 7 ? ladder[k] : MPT_WL_NO_BUDGET;
+    return w;
+}
+
 struct Lane {
     hipStream_t stream = nullptr;
     QueueDev q[2] = {};
@@ -89,7 +99,7 @@ struct mpt_ctx {
     size_t occ_lds = 0;
     int occ_per_cu = 0;
     bool time_kernels = true;
-    WaveBudgets budgets = {{8, 24, 72, 0x7FFFFFFF, 0x7FFFFFFF}};  // box-test loop trips per step of ring 0..3 (measured best
+    WaveBudgets budgets = default_budgets();  // box-test loop trips per step of ring 0..3 (measured best
                                                         // ladder; an unlimited ring-3 budget leaves ring 4 unused)
     uint32_t wl_min = 64, wl_div = 16;  // guided path-id claims: max(wl_min, remaining / (wl_div * waves))
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
@@ -180,17 +190,26 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_LDS_BYTES"))) ctx->lds_budget = (size_t)atol(e);
     ctx->time_kernels = !((e = getenv("MPT_NO_KERNEL_EVENTS")) && atoi(e));
     if ((e = getenv("MPT_WL_BLOCK")) && atoi(e) >= 64) ctx->wl_block = (uint32_t)atoi(e) & ~63u;
-    if ((e = getenv("MPT_BUDGETS"))) {  // e.g. "6,12,24,48"
-        unsigned v[4] = {6, 12, 24, 48};
-        int got = sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]);
-        for (int k = 0; k < 4; ++k) {
-            if (k >= got) v[k] = v[k - 1] * 2;
-            ctx->budgets.b[k] = v[k] < 1 ? 1 : v[k];
+    if ((e = getenv("MPT_BUDGETS"))) {  // e.g. "8,20,50,125": box-test trips per step of ring 0, 1, ... (the last ring has none)
+        unsigned prev = 4;
+        const char* q = e;
+        for (uint32_t k = 0; k + 1 < MPT_WL_LEVELS; ++k) {
+            unsigned v = 0;
+            int used = 0;
+            if (q && sscanf(q, "%u%n", &v, &used) == 1) {
+                q += used;
+                if (*q == ',') ++q;
+            } else {
+                v = prev * 2;
+                q = nullptr;
+            }
+            ctx->budgets.b[k] = v < 1 ? 1 : v;
+            prev = ctx->budgets.b[k];
         }
     }
     if ((e = getenv("MPT_LIGHT_BUDGET")) && atoi(e) >= 1) {  // one number: geometric ladder b, 2b, 4b, 8b
         uint32_t b = (uint32_t)atoi(e);
-        for (int k = 0; k < 4; ++k) ctx->budgets.b[k] = b > (1u << 28) ? b : b << k;
+        for (uint32_t k = 0; k + 1 < MPT_WL_LEVELS; ++k) ctx->budgets.b[k] = b > (1u << 28) ? b : std::min<uint64_t>((uint64_t)b << k, MPT_WL_NO_BUDGET);
     }
     if ((e = getenv("MPT_WL_MIN")) && atoi(e) >= 64) ctx->wl_min = (uint32_t)atoi(e) & ~63u;
     if ((e = getenv("MPT_TILE_ORDER"))) ctx->tile_order_mode = atoi(e);
@@ -828,7 +847,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
                 HIPCHK(hipMalloc(&r.dt, n * 16));
                 HIPCHK(hipMalloc(&r.tl, n * 16));
                 HIPCHK(hipMalloc(&r.ia, n * 16));
-                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 128));  // + room for the MPT_DEBUG_WAVE_TIMES records
+                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 128 + 1024));  // + room for the MPT_DEBUG_WAVE_TIMES records
                 L.ring_waves = waves;
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
@@ -1215,10 +1234,17 @@ extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s
 #ifdef MPT_DEBUG_WAVE_TIMES
 static mpt_ctx* g_dbg_ctx = nullptr;
 extern "C" void mpt_debug_bind(mpt_ctx* ctx) { g_dbg_ctx = ctx; }
+extern "C" int mpt_debug_reset() {   // zero the diagnostics block behind lane 0's rings
+    mpt_ctx* ctx = g_dbg_ctx;
+    const Lane& L = ctx->lane[0];
+    if (!L.ring.tv) return -1;
+    const size_t off = L.ring_waves * MPT_WL_LEVELS * MPT_WL_RING;
+    return (int)hipMemset((char*)L.ring.tv + off * 16, 0, L.ring_waves * 128 + 1024);
+}
 extern "C" int mpt_debug_wave_times(unsigned long long* out, int n) {
     mpt_ctx* ctx = g_dbg_ctx;
     const Lane& L = ctx->lane[0];
     const size_t off = L.ring_waves * MPT_WL_LEVELS * MPT_WL_RING;
-    return (int)hipMemcpy(out, (const char*)L.ring.tv + off * 16, (size_t)n * 128, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out, (const char*)L.ring.tv + off * 16, (size_t)n * 128 + 1024, hipMemcpyDeviceToHost);
 }
 #endif

@@ -437,13 +437,15 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 // any result: every ray writes only its own path's slot.
 // Why budgets: a wave runs as long as its slowest lane, and bounce rays are heavy-tailed on this kind of scene — 88 %
 // need <= 8 box tests, 10 % need 30-160 (they cross the mesh): a full wave of bounce rays used only 14 % of its
-// box-test lane slots.  Budgets 8/24/72/inf sort rays by remaining work (a radix sort on log3 of the work), so every
+// box-test lane slots.  Budgets 8/20/50/125/inf (mpt_hip.hip: default_budgets) sort rays by remaining work, so every
 // step runs rays of similar length (measured: box-test lane slots per ray 37.8 -> 17.8, VALU instructions per ray
 // 40 -> 24).  A parked ray resumes with exactly the state it stopped with and sees the
 // same sequence of tests: results are bit-identical.
 // Capacity: steps on rings never increase the total number of queued rays (64 out, <= 64 in) and a primary step
 // (+<= 64) runs only when every ring holds < 64, so the total never exceeds 64 * LEVELS + 64 = 384 < MPT_WL_RING.
+#ifndef MPT_WL_LEVELS
 #define MPT_WL_LEVELS 5u
+#endif
 #define MPT_WL_RING 512u       // records per ring
 #define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
 #define MPT_WL_NO_BUDGET 0x7FFFFFFFu  // budgets at or above this mean "run to completion"
@@ -651,6 +653,9 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         const int park_ring = level + 1;  // where unfinished queries go
         bool alive = false, parked = false;
         MPT_TOC(reg_fetch, tic_);
+#ifdef MPT_DEBUG_WAVE_TIMES
+        const WorkCount wc0 = wc;
+#endif
         if (valid) {
             bool done;
             if (budgeted)
@@ -661,6 +666,20 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                                                                 0xFFFFFFFFu, wc);
             if (fresh) n_rays++;  // a resumed query was counted when it started
             MPT_TOC(reg_trace, tic_);
+#ifdef MPT_DEBUG_WAVE_TIMES
+            if (COUNT) {  // per-level divergence diagnostics: [level + 1][steps, box trips, box lane work, prim trips, prim lane work]
+                unsigned long long* lv = (unsigned long long*)(ring.tv + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING) +
+                                         16ull * n_waves + 8ull * (unsigned)(level + 1);
+                if (first_active_lane()) atomicAdd(lv + 0, 1ull);
+                // the per-wave trip counters live in whichever lane was first active at the time: sum over lanes
+                if (wc.node_iters != wc0.node_iters) atomicAdd(lv + 1, (unsigned long long)(wc.node_iters - wc0.node_iters));
+                if (wc.prim_iters != wc0.prim_iters) atomicAdd(lv + 3, (unsigned long long)(wc.prim_iters - wc0.prim_iters));
+                atomicAdd(lv + 2, (unsigned long long)(wc.node_visits - wc0.node_visits));
+                atomicAdd(lv + 4, (unsigned long long)(wc.prim_tests - wc0.prim_tests));
+                atomicAdd(lv + 5, 1ull);  // rays in the step
+                if (done) atomicAdd(lv + 6, 1ull);
+            }
+#endif
             if (done) {
                 alive = shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, best_prim);
                 if (!alive)

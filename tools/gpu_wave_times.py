@@ -10,13 +10,17 @@ W, H = 1920, 1080
 ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
 L = capi.load()
 L.mpt_debug_bind(ctx.h)
+flags = capi.FLAG_COUNT_WORK if os.environ.get("COUNT") else 0
 for rep in range(2):
+    if rep: L.mpt_debug_reset()
     ctx.clear_sum(); ctx.reset_stats()
-    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2)
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2, flags=flags)
 st = ctx.stats()
 n = int(os.environ.get("WAVES", "6144"))
-buf = np.zeros((2, n, 8), np.uint64)
-L.mpt_debug_wave_times(buf.ctypes.data_as(C.c_void_p), n)
+raw = np.zeros(2 * n * 8 + 128, np.uint64)
+L.mpt_debug_wave_times(raw.ctypes.data_as(C.c_void_p), n)
+buf = raw[:2 * n * 8].reshape(2, n, 8)
+lv = raw[2 * n * 8:].reshape(16, 8).astype(np.float64)
 reg = buf[1].astype(np.float64)
 buf = buf[0]
 t0 = buf[:, 0].min()
@@ -46,3 +50,14 @@ names = ["step choice + claim", "ray fetch (primary generation / ring pop)", "cl
 print("shader-clock cycles by region (sum over waves, %% of the total of %.3g):" % tot)
 for i, nm in enumerate(names): print("  %-44s %5.1f %%" % (nm, 100 * reg[:, i].sum() / tot))
 print("  inside closest hit: box-test loop %.1f %%, leaf (primitive) loop %.1f %% of the total" % (100 * reg[:, 5].sum() / tot, 100 * reg[:, 6].sum() / tot))
+
+if flags:
+    print("per step kind (COUNT build): steps, rays/step, done %, box trips/step, box lane utilisation, prim trips/step, prim lane utilisation, share of all box+prim wave trips")
+    names = ["primary", "ring 0", "ring 1", "ring 2", "ring 3", "ring 4", "drain"]
+    tot = (lv[:7, 1] * 26 + lv[:7, 3] * 70).sum()
+    for i, nm in enumerate(names):
+        st_, bt, bw, pt, pw, rays, dn = lv[i, :7]
+        if st_ == 0: continue
+        print("  %-8s steps %9d  rays/step %5.1f  done %5.1f %%  box trips %7.1f util %4.1f %%  prim trips %6.1f util %4.1f %%  cost share %4.1f %%" % (
+            nm, st_, rays / st_, 100 * dn / max(1, rays), bt / st_, 100 * bw / max(1, 64 * bt), pt / st_, 100 * pw / max(1, 64 * pt),
+            100 * (bt * 26 + pt * 70) / tot))
