@@ -246,7 +246,8 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
 // wave run the primitive loop, for all lanes with a pending leaf at once.
 template <bool COUNT, bool ALL_LDS, bool BUDGETED>
 __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d, uint32_t& node,
-                                                   float& best_t, int& best_prim, uint32_t budget, WorkCount& wc) {
+                                                   float& best_t, int& best_prim, uint32_t budget, WorkCount& wc,
+                                                   uint32_t min_active = 0u) {
     const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;  // PathTracing.h:61 (per call there)
     const uint32_t n_nodes = sc.n_nodes, n_lds = sc.n_lds_nodes;
     // A direction with a NaN component (normalize of a zero vector: e.g. a refraction at the critical angle whose
@@ -311,8 +312,12 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
             leaf_test<COUNT>(sc, lds_nodes, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
         }
         MPT_TOC(wc.t_leaf, tic_);
-        // the wave goes round again only while some lane still has nodes to visit and budget is left
-        if (__ballot(i < n_nodes && (!BUDGETED || trips < budget)) == 0ull) break;
+        // the wave goes round again only while some lane still has nodes to visit and budget is left ...
+        const unsigned long long going = __ballot(i < n_nodes && (!BUDGETED || trips < budget));
+        if (going == 0ull) break;
+        // ... and, in a budgeted step, while enough lanes are still working: the stragglers of a step are parked and
+        // meet other stragglers in the next ring instead of holding 64 lanes for their long walks
+        if (BUDGETED && (uint32_t)__popcll(going) < min_active) break;
     }
     node = i;
     return i >= n_nodes;

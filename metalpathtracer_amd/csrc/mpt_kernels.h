@@ -458,6 +458,7 @@ struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING]
 };
 struct WaveBudgets {
     uint32_t b[MPT_WL_LEVELS]; // box-test loop trips granted per step of ring k (last entry unused: unlimited)
+    uint32_t min_active[MPT_WL_LEVELS];  // a step of ring k ends early once fewer lanes than this are still traversing
 };
 
 // Operating point (measured, 1080p x 256 spp): with the whole BVH in LDS the kernel is VALU-bound and the 64-VGPR cap of
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         uint32_t node = 0;
         float best_t = INFINITY;
         int best_prim = -1;
-        uint32_t budget = 0xFFFFFFFFu;
+        uint32_t budget = 0xFFFFFFFFu, min_active = 0u;
         bool fresh = false;  // this lane starts a new closest-hit query (primary ray or ring-0 record)
         if (level < 0) {
             fresh = true;
@@ -615,7 +616,10 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                     my_off = cnt[k] - tk + (lane - assigned);  // newest records first: they are still in L2
 #endif
                 }
-                if (level == k) budget = budgets.b[k];
+                if (level == k) {
+                    budget = budgets.b[k];
+                    min_active = budgets.min_active[k];
+                }
 #ifdef MPT_WL_FIFO
                 head[k] = (head[k] + tk) & M;
 #endif
@@ -649,8 +653,10 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             }
         }
         // the last ring never has a budget; a ring whose budget is "none" runs the plain (unsynchronised) loop
-        const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS - 1 && budget < MPT_WL_NO_BUDGET;
-        const int park_ring = level + 1;  // where unfinished queries go
+        // (the last ring has no trip budget; with a min_active rule its stragglers go back on top of the same ring)
+        const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS &&
+                              ((level < (int)MPT_WL_LEVELS - 1 && budget < MPT_WL_NO_BUDGET) || min_active != 0u);
+        const int park_ring = level + 1 < (int)MPT_WL_LEVELS ? level + 1 : (int)MPT_WL_LEVELS - 1;  // where unfinished queries go
         bool alive = false, parked = false;
         MPT_TOC(reg_fetch, tic_);
 #ifdef MPT_DEBUG_WAVE_TIMES
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             bool done;
             if (budgeted)
                 done = closest_hit_resume<COUNT, ALL_LDS, true>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
-                                                               budget, wc);
+                                                               budget, wc, min_active);
             else
                 done = closest_hit_resume<COUNT, ALL_LDS, false>(pp.scene, lds_nodes, ps.o, ps.d, node, best_t, best_prim,
                                                                 0xFFFFFFFFu, wc);
