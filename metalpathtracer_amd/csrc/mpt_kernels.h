@@ -626,6 +626,10 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 cnt[k] -= tk;
                 assigned += tk;
             }
+            // merged drain step: no trip budget, but the stragglers of a step (fewer than a third of the lanes it
+            // started with) go back to the last ring and are traced together once the rest is gone (4.76 -> 4.54 ms
+            // for a 32-spp pass)
+            if (level == (int)MPT_WL_LEVELS && assigned >= 12u) min_active = assigned / 3u;
             if (take) {
                 const uint32_t at = wbase + my_ring * MPT_WL_RING + my_off;
                 const float4 a = ring.od[at], b = ring.dt[at], cc = ring.tl[at];
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         }
         // the last ring never has a budget; a ring whose budget is "none" runs the plain (unsynchronised) loop
         // (the last ring has no trip budget; with a min_active rule its stragglers go back on top of the same ring)
-        const bool budgeted = level >= 0 && level < (int)MPT_WL_LEVELS &&
+        const bool budgeted = level >= 0 && (level < (int)MPT_WL_LEVELS || min_active != 0u) &&
                               ((level < (int)MPT_WL_LEVELS - 1 && budget < MPT_WL_NO_BUDGET) || min_active != 0u);
         const int park_ring = level + 1 < (int)MPT_WL_LEVELS ? level + 1 : (int)MPT_WL_LEVELS - 1;  // where unfinished queries go
         bool alive = false, parked = false;
