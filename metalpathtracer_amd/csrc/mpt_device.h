@@ -244,6 +244,9 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
 //   exact state to resume from: the ray sees the same sequence of tests either way, so results do not change).
 // "while-while" form: every lane first walks box tests until IT has a leaf to test (or is done); only then does the
 // wave run the primitive loop, for all lanes with a pending leaf at once.
+#ifndef MPT_LEAF_EARLY
+#define MPT_LEAF_EARLY 8u
+#endif
 template <bool COUNT, bool ALL_LDS, bool BUDGETED>
 __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d, uint32_t& node,
                                                    float& best_t, int& best_prim, uint32_t budget, WorkCount& wc,
@@ -261,7 +264,13 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
     MPT_TIC(tic_);
     for (;;) {
         uint32_t leaf_first = 0, leaf_count = 0;
+        const uint32_t n_entered = (uint32_t)__popcll(__ballot(i < n_nodes && (!BUDGETED || trips < budget)));
         while (i < n_nodes && (!BUDGETED || trips < budget)) {
+            // When fewer than 1/8 of the lanes that entered this search are still looking for their next leaf, the
+            // others — who hold a leaf — stop waiting: the leaf phase runs now and the searchers resume afterwards
+            // from where they are (each lane still sees its own sequence of tests).  In the deep rings most box-loop
+            // lane slots were such waits (utilisation 19-42 %); 28.7 -> 27.4 ms, thresholds 1/6 .. 1/32 all help.
+            if ((uint32_t)__popcll(__ballot(true)) * MPT_LEAF_EARLY < n_entered) break;
             float4 n0, n1;
             if (ALL_LDS || i < n_lds) {
                 const v4f a = lds_nodes[2 * i], b = lds_nodes[2 * i + 1];
