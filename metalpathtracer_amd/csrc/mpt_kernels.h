@@ -461,13 +461,14 @@ struct WaveBudgets {
     uint32_t min_active[MPT_WL_LEVELS];  // a step of ring k ends early once fewer lanes than this are still traversing
 };
 
-// Operating point (measured, 1080p x 256 spp): with the whole BVH in LDS the kernel is VALU-bound and the 64-VGPR cap of
-// 8 waves/SIMD costs 92 B/lane of scratch spills in the hot loops — 6 waves/SIMD (80 VGPRs, no scratch, workgroups of
-// 768) is 19 % faster on scene.xml (36.8 -> 30.9 ms).  Scenes whose nodes come from L2 are latency-bound and keep
-// 8 waves/SIMD (1 M triangles: 74 ms vs 81 ms with 6; bunny x20: 2 % better with 8).  7 waves/SIMD (896, 72 VGPRs,
-// 48 B scratch, waves unevenly spread over the SIMDs) is worse than both.
-#define MPT_WL_THREADS(ALL_LDS) ((ALL_LDS) ? 768 : 1024)
-#define MPT_WL_WAVES(ALL_LDS) ((ALL_LDS) ? 6 : MPT_MIN_WAVES)
+// Operating point (measured, 1080p x 256 spp): the kernel is VALU-issue-bound and the 64-VGPR cap of 8 waves/SIMD costs
+// 92-150 B/lane of scratch spills in the hot loops — 6 waves/SIMD (80 VGPRs, no scratch with the BVH in LDS, workgroups
+// of 768) is 19 % faster on scene.xml (36.8 -> 30.9 ms).  Scenes whose nodes come from L2 preferred 8 waves/SIMD while
+// the kernel was still latency-sensitive (FIFO rings, cached result slots); with the current kernel 6 waves/SIMD wins
+// there too (bunny x20 6.15 -> 6.82 Grays/s, 1 M triangles 4.40 -> 5.25).  7 waves/SIMD (896 threads, 72 VGPRs, waves
+// unevenly spread over the SIMDs) and 5 are worse than both.
+#define MPT_WL_THREADS(ALL_LDS) 768
+#define MPT_WL_WAVES(ALL_LDS) 6
 template <bool COUNT, bool ALL_LDS>
 __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) void k_wavelocal(PassParams pp, WaveRings ring, WaveBudgets budgets,
                                                                  uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
