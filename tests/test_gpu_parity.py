@@ -520,3 +520,24 @@ def test_async_renders_overlap_and_match_the_serial_result(gpu_ctx):
     both = gpu_ctx.read_sum()
     ref2, _ = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, max_depth=8, accumulate=1, sample_count=2, seed=(4, 2), threads=8)
     np.testing.assert_array_equal(both.view(np.uint32), ref2.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,W,H,cam,depth,spp,bsdf", [
+    ("scene.xml", 160, 90, None, 8, 8, 0),
+    ("cornell.xml", 96, 96, CORNELL_CAM, 32, 8, 0),
+    ("glass.xml", 128, 72, None, 16, 8, 1),
+    ("bunny20.xml", 96, 54, None, 8, 2, 0),
+])
+def test_production_kernel_variant_bit_exact(gpu_ctx, name, W, H, cam, depth, spp, bsdf):
+    """The same comparison without MPT_FLAG_COUNT_WORK: that is the kernel instantiation bench.py and users run
+    (no work counters, result slots not poisoned)."""
+    from metalpathtracer_amd import capi
+    buf, uo = setup(gpu_ctx, name, W, H, cam=cam)
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, seed=(11, 5))
+    got = gpu_ctx.read_sum()
+    ref, ct = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, accumulate=1,
+                        sample_count=spp, seed=(11, 5), threads=8)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    st = gpu_ctx.stats()
+    assert (st["paths"], st["rays"]) == (ct["paths"], ct["rays"])
