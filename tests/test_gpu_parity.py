@@ -534,6 +534,7 @@ def test_production_kernel_variant_bit_exact(gpu_ctx, name, W, H, cam, depth, sp
     from metalpathtracer_amd import capi
     buf, uo = setup(gpu_ctx, name, W, H, cam=cam)
     gpu_ctx.clear_sum()
+    gpu_ctx.reset_stats()
     gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, seed=(11, 5))
     got = gpu_ctx.read_sum()
     ref, ct = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, accumulate=1,
