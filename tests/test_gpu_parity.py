@@ -542,3 +542,15 @@ def test_production_kernel_variant_bit_exact(gpu_ctx, name, W, H, cam, depth, sp
     np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
     st = gpu_ctx.stats()
     assert (st["paths"], st["rays"]) == (ct["paths"], ct["rays"])
+
+
+def test_randomised_cases_bit_exact():
+    """60 random (scene, size, sample range, depth, seed, BSDF mode, pipeline, shard count, sync/async) cases, each
+    compared bit for bit with the oracle (tools/gpu_fuzz_parity.py)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, CASES="60", SEED="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz_parity.py")], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "60 cases, 0 mismatches" in r.stdout
