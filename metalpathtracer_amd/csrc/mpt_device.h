@@ -142,6 +142,7 @@ struct WorkCount {
     uint32_t node_iters, prim_iters, outer_iters;  // per WAVE loop trips (lane 0 only): x64 = issued lane slots
 #ifdef MPT_DEBUG_WAVE_TIMES
     unsigned long long t_box, t_leaf;              // diagnostics build: shader-clock cycles spent in the two loops
+    uint32_t wait_leaf, wait_done;                 // box-loop trips this lane idled holding a leaf / after finishing
 #endif
 };
 #ifdef MPT_DEBUG_WAVE_TIMES
@@ -265,7 +266,13 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
     for (;;) {
         uint32_t leaf_first = 0, leaf_count = 0;
         const uint32_t n_entered = (uint32_t)__popcll(__ballot(i < n_nodes && (!BUDGETED || trips < budget)));
+#ifdef MPT_DEBUG_WAVE_TIMES
+        uint32_t my_trips = 0;
+#endif
         while (i < n_nodes && (!BUDGETED || trips < budget)) {
+#ifdef MPT_DEBUG_WAVE_TIMES
+            my_trips++;
+#endif
             // When fewer than 1/8 of the lanes that entered this search are still looking for their next leaf, the
             // others — who hold a leaf — stop waiting: the leaf phase runs now and the searchers resume afterwards
             // from where they are (each lane still sees its own sequence of tests).  In the deep rings most box-loop
@@ -315,6 +322,13 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
         }
         // a lane that left the loop early (leaf found / done) adopts the trips the rest of the wave made meanwhile
         if (BUDGETED) trips = wave_max_u32(trips);
+#ifdef MPT_DEBUG_WAVE_TIMES
+        if (COUNT) {
+            const uint32_t round_trips = wave_max_u32(my_trips);
+            if (leaf_count != 0u) wc.wait_leaf += round_trips - my_trips;
+            else wc.wait_done += round_trips - my_trips;   // finished, out of budget, or cut by the early leave
+        }
+#endif
         MPT_TOC(wc.t_box, tic_);
         if (leaf_count != 0u) {
             if (COUNT && first_active_lane()) wc.outer_iters++;

@@ -688,6 +688,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 atomicAdd(lv + 2, (unsigned long long)(wc.node_visits - wc0.node_visits));
                 atomicAdd(lv + 4, (unsigned long long)(wc.prim_tests - wc0.prim_tests));
                 atomicAdd(lv + 5, 1ull);  // rays in the step
+                if (wc.wait_leaf != wc0.wait_leaf) atomicAdd(lv + 7, (unsigned long long)(wc.wait_leaf - wc0.wait_leaf));
                 if (done) atomicAdd(lv + 6, 1ull);
             }
 #endif

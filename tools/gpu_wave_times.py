@@ -57,7 +57,8 @@ if flags:
     tot = (lv[:7, 1] * 26 + lv[:7, 3] * 70).sum()
     for i, nm in enumerate(names):
         st_, bt, bw, pt, pw, rays, dn = lv[i, :7]
+        wl = lv[i, 7]
         if st_ == 0: continue
-        print("  %-8s steps %9d  rays/step %5.1f  done %5.1f %%  box trips %7.1f util %4.1f %%  prim trips %6.1f util %4.1f %%  cost share %4.1f %%" % (
+        print("  %-8s steps %9d  rays/step %5.1f  done %5.1f %%  box trips %7.1f util %4.1f %%  prim trips %6.1f util %4.1f %%  cost share %4.1f %%  box slots waiting with a leaf %4.1f %%" % (
             nm, st_, rays / st_, 100 * dn / max(1, rays), bt / st_, 100 * bw / max(1, 64 * bt), pt / st_, 100 * pw / max(1, 64 * pt),
-            100 * (bt * 26 + pt * 70) / tot))
+            100 * (bt * 26 + pt * 70) / tot, 100 * wl / max(1, 64 * bt)))
