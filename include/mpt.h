@@ -151,7 +151,8 @@ int mpt_read_sum(mpt_ctx* ctx, float* rgba_host);
 
 int mpt_get_stats(mpt_ctx* ctx, mpt_stats* out);
 int mpt_reset_stats(mpt_ctx* ctx);
-void* mpt_stream(mpt_ctx* ctx);                      /* hipStream_t the context launches on           */
+void* mpt_stream(mpt_ctx* ctx);                      /* hipStream_t of uploads, clears, mpt_draw and serial mpt_render
+                                                        (mpt_render_async alternates between this and a second stream) */
 int mpt_synchronize(mpt_ctx* ctx);
 
 /* Device-side closest-hit for a batch of rays (unit tests of firstHitBVH, PathTracing.h:75-204).
