@@ -10,7 +10,10 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
+#include <future>
 #include <limits>
+#include <thread>
 
 namespace MetalCppPathTracer {
 
@@ -40,7 +43,6 @@ struct BuildContext {
     std::vector<float3> lo, hi;      // per-primitive bounds (R/Scene/Scene.h:199-209)
     std::vector<float> key[3];       // data0[axis]
     std::vector<float3> cen;         // centroid of the bounds (binned builder)
-    std::vector<Box> prefix, suffix; // sweep scratch, reused across nodes
 
     BuildContext(const std::vector<Primitive>& p, std::vector<size_t>& o, std::vector<BVHNode>& n)
         : prims(p), order(o), nodes(n) {
@@ -66,14 +68,49 @@ struct BuildContext {
         }
     }
 
-    int emitLeaf(size_t start, size_t end, const Box& b) {
+    static int emitLeaf(std::vector<BVHNode>& out, size_t start, size_t end, const Box& b) {
         BVHNode n;
         n.boundsMin = b.lo;
         n.boundsMax = b.hi;
         n.leftFirst = static_cast<int>(start);
         n.count = static_cast<int>(end - start);
-        nodes.push_back(n);
-        return static_cast<int>(nodes.size()) - 1;
+        out.push_back(n);
+        return static_cast<int>(out.size()) - 1;
+    }
+
+    // Subtrees are independent once their primitive range is fixed, so the two children of a big node are built
+    // concurrently — the left one as a task into its own node list, the right one by the calling thread — and spliced
+    // behind the parent in the sequential pre-order (parent, left subtree, right subtree), child indices shifted by
+    // the splice offset.  Every decision depends only on the range's content, so the tree is identical to the
+    // sequential build (tests/test_host_scene.py); the work inside one node (the chained sorts) stays sequential.
+    // `forks` = levels of forking left below this node (0 = build in place).
+    template <class BuildFn>
+    void buildChildren(std::vector<BVHNode>& out, int self, size_t start, size_t mid, size_t end, int forks, BuildFn fn) {
+        int left, right;
+        if (forks > 0 && end - start >= 8192) {
+            std::vector<BVHNode> l, r;
+            auto task = std::async(std::launch::async, [&] { fn(l, start, mid, forks - 1); });
+            fn(r, mid, end, forks - 1);
+            task.get();
+            auto splice = [&out](const std::vector<BVHNode>& sub) {
+                const int off = static_cast<int>(out.size());
+                for (BVHNode n : sub) {
+                    if (n.count <= 0 && sub.size() > 1) {  // internal node: (left child, -right child)
+                        n.leftFirst += off;
+                        n.count -= off;
+                    }
+                    out.push_back(n);
+                }
+                return off;
+            };
+            left = splice(l);
+            right = splice(r);
+        } else {
+            left = fn(out, start, mid, 0);
+            right = fn(out, mid, end, 0);
+        }
+        out[self].leftFirst = left;
+        out[self].count = -right;
     }
 
     Box rangeBox(size_t start, size_t end) const {
@@ -88,9 +125,10 @@ struct BuildContext {
     }
 
     // ---- reference-compatible builder -------------------------------------------------------------------
-    int buildSweep(size_t start, size_t end) {
+    int buildSweep(std::vector<BVHNode>& out, size_t start, size_t end, int forks) {
+        static thread_local std::vector<Box> prefix, suffix;  // sweep scratch, reused across the nodes of a thread
         const Box bounds = rangeBox(start, end);
-        const int self = emitLeaf(start, end, bounds);
+        const int self = emitLeaf(out, start, end, bounds);
         const size_t n = end - start;
         if (n <= 8) return self;
         const float parentArea = boxArea(bounds.lo, bounds.hi);
@@ -129,17 +167,15 @@ struct BuildContext {
         }
         if (bestAxis < 0) return self;
         sortRange(start, end, bestAxis);
-        const int left = buildSweep(start, bestSplit);
-        const int right = buildSweep(bestSplit, end);
-        nodes[self].leftFirst = left;
-        nodes[self].count = -right;
+        buildChildren(out, self, start, bestSplit, end, forks,
+                      [this](std::vector<BVHNode>& o, size_t a, size_t b, int f) { return buildSweep(o, a, b, f); });
         return self;
     }
 
     // ---- fast builder: 16-bin SAH on centroids (image-equivalent tree, different topology) ----------------
-    int buildBinned(size_t start, size_t end) {
+    int buildBinned(std::vector<BVHNode>& out, size_t start, size_t end, int forks) {
         const Box bounds = rangeBox(start, end);
-        const int self = emitLeaf(start, end, bounds);
+        const int self = emitLeaf(out, start, end, bounds);
         const size_t n = end - start;
         if (n <= 4) return self;
         Box cb;
@@ -204,10 +240,8 @@ struct BuildContext {
             mid = static_cast<size_t>(it - order.begin());
             if (mid == start || mid == end) mid = start + n / 2;
         }
-        const int left = buildBinned(start, mid);
-        const int right = buildBinned(mid, end);
-        nodes[self].leftFirst = left;
-        nodes[self].count = -right;
+        buildChildren(out, self, start, mid, end, forks,
+                      [this](std::vector<BVHNode>& o, size_t a, size_t b, int f) { return buildBinned(o, a, b, f); });
         return self;
     }
 };
@@ -257,10 +291,15 @@ void Scene::buildBVH(BuildMode mode) {
         return;
     }
     BuildContext ctx(primitives_, primitiveIndices_, nodes_);
+    // levels of forking: 2^forks concurrent subtree tasks at most (MPT_BUILD_THREADS=1 builds sequentially)
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("MPT_BUILD_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(e)));
+    int forks = 0;
+    while ((1u << forks) < threads && forks < 6) ++forks;
     if (mode == BuildMode::ReferenceSweep)
-        ctx.buildSweep(0, primitives_.size());
+        ctx.buildSweep(nodes_, 0, primitives_.size(), forks);
     else
-        ctx.buildBinned(0, primitives_.size());
+        ctx.buildBinned(nodes_, 0, primitives_.size(), forks);
 }
 
 int Scene::getBVHDepth() const {

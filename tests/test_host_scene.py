@@ -165,3 +165,28 @@ def test_buffers_before_build_bvh_are_well_defined():
     P = sc.getPrimitiveCount()
     assert bvh.shape[0] == 0 and prims.shape[0] == P and mats.shape[0] == P
     assert idx.tolist() == list(range(P))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_parallel_bvh_build_is_identical_to_the_sequential_one(mode, monkeypatch):
+    """Subtrees of big nodes are built concurrently and spliced in pre-order: the arrays must not depend on the
+    number of threads (MPT_BUILD_THREADS=1 is the plain sequential recursion)."""
+    import os
+    import numpy as np
+    from conftest import ASSETS
+    from metalpathtracer_amd import host
+
+    def build(threads):
+        monkeypatch.setenv("MPT_BUILD_THREADS", str(threads))
+        sc = host.Scene()
+        st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ASSETS, "bunny20.xml"), sc)
+        assert st == 0
+        sc.buildBVH(mode)
+        return sc.buffers()
+
+    seq = build(1)
+    for threads in (2, 8, 64):
+        par = build(threads)
+        for a, b in zip(seq, par):
+            assert a.shape == b.shape
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
