@@ -226,6 +226,17 @@ def test_error_paths(gpu_ctx):
     with pytest.raises(capi.MptError) as e:
         ctx.render(sample_count=1)
     assert e.value.status == 1  # uniforms.screenSize != resize
+    with pytest.raises(capi.MptError) as e:
+        ctx.render_async(sample_count=1)
+    assert e.value.status == 1  # the asynchronous entry point validates the same way, nothing is left in flight
+    ctx.wait()
+    ctx.set_uniforms(host.make_uniforms(32, 32, sc.getPrimitiveCount()))
+    with pytest.raises(capi.MptError) as e:
+        ctx.render_async(sample_count=1, max_depth=33)
+    assert e.value.status == 1
+    ctx.render_async(rng_mode=capi.RNG_PHILOX, sample_count=2)      # and a valid one still works afterwards;
+    ctx.resize(16, 16)                                              # resize waits for it by itself
+    assert ctx.stats()["paths"] == 32 * 32 * 2
     ctx.close()
 
 
