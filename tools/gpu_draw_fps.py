@@ -14,6 +14,6 @@ for W, H in ((1280, 720), (1920, 1080), (3840, 2160)):
         for f in range(n + 10):
             if f == 10: ctx.synchronize(); t0 = time.perf_counter()
             ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), random_seed=seeds, frame_count=f))
-            ctx.draw(rng_mode=rng_mode, max_depth=32, sample_begin=f, sample_count=1)
+            ctx.draw(rng_mode=rng_mode, max_depth=32, sample_begin=f, sample_count=1, pipeline=int(os.environ.get("PIPE", "2")))
         ctx.synchronize(); dt = time.perf_counter() - t0
         print("%dx%d %s: %.3f ms/frame (%.0f frames/s, %.1f Mpaths/s)" % (W, H, name, dt * 1e3 / n, n / dt, W * H * n / dt / 1e6), flush=True)
