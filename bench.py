@@ -62,6 +62,20 @@ def measured_traffic(pipe, rays_per_launch):
         return None
 
 
+def issue_profile(pipe):
+    """What actually bounds the dominant kernel (from the same committed PMC passes): VALU wave-instructions per ray and
+    the fraction of their lane slots that did work."""
+    try:
+        if pipe != 2:
+            return None
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        return {"valu_wave_instr_per_ray": prof["valu_wave_instr_per_ray"],
+                "valu_lane_utilisation": prof["valu_lane_utilisation"], "l2_hit_rate": prof["l2_hit_rate"],
+                "source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, same workload)"}
+    except Exception:
+        return None
+
+
 def host_cores():
     """Threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota when there is one."""
     n = max(1, len(os.sched_getaffinity(0)))
@@ -242,8 +256,12 @@ def main():
                 "algorithmic_bytes_per_launch": b_ray * rays_per_launch,
                 "note": "achieved = SURVEY 8(d) algorithmic bytes/ray x rays per launch / avg launch time; frac > 1 "
                         "means the kernel is not HBM-bound: the scene (0.5 MB) is served from LDS/L2; `traffic` = measured "
-                        "L2<->fabric bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)",
+                        "L2<->fabric bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json); the kernel is "
+                        "VALU-issue-bound, see `issue`",
             }
+            issue = issue_profile(pipe)
+            if issue:
+                out["roofline"]["issue"] = issue
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
