@@ -190,3 +190,53 @@ def test_parallel_bvh_build_is_identical_to_the_sequential_one(mode, monkeypatch
         for a, b in zip(seq, par):
             assert a.shape == b.shape
             np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bvh_is_a_valid_partition_with_enclosing_boxes(mode, seed):
+    """Structural invariants of both host builders on random scenes (spheres + triangles, clusters, duplicates):
+    the leaves partition the primitive index list, every node box encloses its primitives, leaves hold <= 8."""
+    import numpy as np
+    from metalpathtracer_amd import host
+    rng = np.random.default_rng(seed)
+    sc = host.Scene()
+    n_s, n_t = int(rng.integers(0, 6)), int(rng.integers(50, 700))
+    for _ in range(n_s):
+        sc.addSphere(tuple(rng.normal(0, 20, 3)), float(rng.uniform(0.5, 30)))
+    centers = rng.normal(0, 15, (5, 3))
+    for k in range(n_t):
+        c = centers[rng.integers(0, 5)]
+        v = c + rng.normal(0, 1.5, (3, 3))
+        if k % 17 == 0:
+            v[1] = v[0]                      # degenerate triangle
+        if k % 29 == 0 and k:
+            v = last                         # exact duplicate of an earlier triangle (equal sort keys)
+        last = v
+        sc.addTriangle(tuple(v[0]), tuple(v[1]), tuple(v[2]))
+    sc.buildBVH(mode)
+    bvh, prims, mats, idx = sc.buffers()
+    P, N = sc.getPrimitiveCount(), sc.getBVHNodeCount()
+    assert P == n_s + n_t and sorted(idx.tolist()) == list(range(P))
+    lo = np.where(prims[:, 0, 3:4] == 1, prims[:, :, :3].min(1), prims[:, 0, :3] - prims[:, 1, 0:1])
+    hi = np.where(prims[:, 0, 3:4] == 1, prims[:, :, :3].max(1), prims[:, 0, :3] + prims[:, 1, 0:1])
+    covered = np.zeros(P, int)
+    stack = [0]
+    seen = 0
+    while stack:
+        n = stack.pop()
+        seen += 1
+        bmin, bmax = bvh[n, 0, :3], bvh[n, 1, :3]
+        first, count = int(bvh[n, 0, 3].view(np.int32)), int(bvh[n, 1, 3].view(np.int32))
+        if count > 0:                                         # leaf: [first, first + count) of the index list
+            assert count <= 8
+            members = idx[first:first + count]
+            covered[first:first + count] += 1
+            assert (lo[members] >= bmin - 0).all() and (hi[members] <= bmax + 0).all()
+        else:                                                 # internal: children (first, -count)
+            l, r = first, -count
+            assert 0 < l < N and 0 < r < N and l != r
+            for c in (l, r):
+                assert (bvh[c, 0, :3] >= bmin).all() and (bvh[c, 1, :3] <= bmax).all()
+                stack.append(c)
+    assert seen == N and (covered == 1).all()
