@@ -264,3 +264,72 @@ def test_zero_texcoord_index_is_accepted_like_tinyobj(ref, tmp_path):
     xml.write_text('<Scene><Mesh file="z.obj" position="0,0,0" albedo="1,1,1" emission="0,0,0"/></Scene>')
     hp, op = loaders(str(xml))
     assert hp.shape[0] == op.shape[0] == 1
+
+
+def test_random_xml_formatting_matches_tinyxml2(ref, tmp_path):
+    """60 <Sphere> elements with randomised formatting (quotes, whitespace, attribute order, number spellings, missing
+    attributes, entities, comments between elements, open/close vs self-closing tags): every value the product and
+    the oracle ingest equals what tinyxml2 + the reference's parseVec3 / FloatAttribute produce."""
+    rng = np.random.default_rng(17)
+
+    def num():
+        v = rng.normal(0, 50)
+        form = int(rng.integers(0, 6))
+        return ["%g" % v, "%.3f" % v, "%e" % v, "%+.2f" % v, "%d" % int(v), ".5" if v > 0 else "-.25"][form]
+
+    def vec(k):
+        sep = [",", ", ", " ,", " , "][int(rng.integers(0, 4))]
+        return sep.join(num() for _ in range(k))
+
+    lines, n = ["<?xml version='1.0' encoding='UTF-8'?>", "<Scene>"], 60
+    for i in range(n):
+        attrs = [("position", vec(int(rng.choice([3, 3, 3, 2, 1])))), ("albedo", vec(3)), ("emission", vec(3))]
+        if rng.random() < 0.8: attrs.append(("radius", num()))
+        if rng.random() < 0.6: attrs.append(("materialType", num()))
+        if rng.random() < 0.6: attrs.append(("emissionPower", num()))
+        if rng.random() < 0.2: attrs.append(("note", "a &amp; b &lt;c&gt; &#65;"))
+        rng.shuffle(attrs)
+        parts = []
+        for k, v in attrs:
+            q = "'" if rng.random() < 0.4 else '"'
+            eq = ["=", " =", "= ", " = "][int(rng.integers(0, 4))]
+            parts.append("%s%s%s%s%s" % (k, eq, q, v, q))
+        body = ("\n      " if rng.random() < 0.3 else " ").join(parts)
+        tag = "<Sphere %s/>" % body if rng.random() < 0.6 else "<Sphere %s></Sphere>" % body
+        if rng.random() < 0.3: lines.append("  <!-- comment %d <Sphere radius='9'/> -->" % i)
+        lines.append("  " + tag)
+    lines.append("</Scene>")
+    xml = tmp_path / "fmt.xml"
+    xml.write_text("\n".join(lines))
+    cnt = C.c_int64()
+    h = ref.ref_xml_open(str(xml).encode(), C.byref(cnt))
+    assert h and cnt.value == n
+    hs = host.Scene()
+    st, _ = host.SceneLoader.LoadSceneFromXML(str(xml), hs)
+    assert st == 0 and hs.getPrimitiveCount() == n
+    _, prims, mats, _ = hs.buffers()
+    osn = ob.OracleScene()
+    assert osn.load_xml(str(xml)) == 0 and osn.prim_count == n
+    op = np.zeros((n, 3, 4), np.float32)
+    ob.lib().orc_scene_pack_prims(osn.h, op.ctypes.data_as(C.POINTER(C.c_float)))
+    libc = C.CDLL(None)
+
+    def parse_vec3(text):       # SceneLoader.cpp:14-18 on the attribute text tinyxml2 returns (NULL -> zeros)
+        x = (C.c_float * 3)()
+        if text is not None:
+            libc.sscanf(text, b"%f,%f,%f", C.byref(x, 0), C.byref(x, 4), C.byref(x, 8))
+        return [x[0], x[1], x[2]]
+
+    for i in range(n):
+        assert ref.ref_xml_name(h, i) == b"Sphere"
+        radius = ref.ref_xml_float_attr(h, i, b"radius", 1.0)
+        mtype = ref.ref_xml_float_attr(h, i, b"materialType", 0.0)
+        power = ref.ref_xml_float_attr(h, i, b"emissionPower", 0.0)
+        pos = parse_vec3(ref.ref_xml_attr(h, i, b"position"))
+        alb = parse_vec3(ref.ref_xml_attr(h, i, b"albedo"))
+        emi = parse_vec3(ref.ref_xml_attr(h, i, b"emission"))
+        for p in (prims, op):
+            assert p[i, 0, :3].tolist() == pos and p[i, 1, 0] == np.float32(radius), i
+        assert mats[i, 0, :3].tolist() == alb and mats[i, 1, :3].tolist() == emi, i
+        assert mats[i, 0, 3] == np.float32(mtype) and mats[i, 1, 3] == np.float32(power), i
+    ref.ref_xml_close(h)
