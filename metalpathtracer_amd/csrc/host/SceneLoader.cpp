@@ -379,14 +379,21 @@ public:
     explicit XmlScanner(const std::string& t) : text_(t) {}
 
     // Collects the element children of the first top-level <Scene>.  Returns Ok / NoSceneRoot / XmlMalformed.
+    // Well-formedness is checked the way tinyxml2's LoadFile does for the constructs a scene file can contain — end
+    // tags must match the open element, every element must be closed, attribute names are unique per element, the
+    // document holds at least one node (element, comment or declaration) — because the reference leaves the scene untouched when LoadFile fails
+    // (R/Scene/SceneLoader.cpp:76-80); tests/test_ingest_vs_ref.py compares accept / reject with the real library.
     SceneLoader::Status children(std::vector<Element>& out) {
         int depth = 0;
         bool inside = false, found = false;
+        std::vector<std::string> open;
+        size_t elements = 0;
         while (pos_ < text_.size()) {
             if (text_[pos_] != '<') {
                 ++pos_;
                 continue;
             }
+            ++elements;  // any markup counts: only a document without a single node is "empty" for tinyxml2
             if (startsWith("<!--")) {
                 if (!skipPast("-->")) return SceneLoader::XmlMalformed;
             } else if (startsWith("<?")) {
@@ -396,6 +403,10 @@ public:
             } else if (startsWith("</")) {
                 size_t close = text_.find('>', pos_);
                 if (close == std::string::npos) return SceneLoader::XmlMalformed;
+                std::string name = text_.substr(pos_ + 2, close - pos_ - 2);
+                while (!name.empty() && std::isspace(static_cast<unsigned char>(name.back()))) name.pop_back();
+                if (open.empty() || open.back() != name) return SceneLoader::XmlMalformed;  // mismatched end tag
+                open.pop_back();
                 --depth;
                 if (inside && depth == 0) inside = false;
                 pos_ = close + 1;
@@ -403,6 +414,11 @@ public:
                 Element e;
                 bool selfClosing = false;
                 if (!openTag(e, selfClosing)) return SceneLoader::XmlMalformed;
+                if (e.name.empty()) return SceneLoader::XmlMalformed;
+                for (size_t a = 0; a < e.attributes.size(); ++a)
+                    for (size_t b = a + 1; b < e.attributes.size(); ++b)
+                        if (e.attributes[a].first == e.attributes[b].first) return SceneLoader::XmlMalformed;
+                if (!selfClosing) open.push_back(e.name);
                 if (depth == 0 && !found && e.name == "Scene") {
                     found = true;
                     inside = !selfClosing;
@@ -412,6 +428,7 @@ public:
                 if (!selfClosing) ++depth;
             }
         }
+        if (!open.empty() || elements == 0) return SceneLoader::XmlMalformed;  // unclosed element / empty document
         return found ? SceneLoader::Ok : SceneLoader::NoSceneRoot;
     }
 

@@ -626,32 +626,45 @@ struct XmlElem {
 };
 // Minimal XML reader for the reference schema (R/scene.xml): comments, a <Scene> root,
 // attribute-only child elements.  Returns the children of <Scene> in document order.
-static bool parse_scene_xml(const std::string& text, std::vector<XmlElem>& out, std::string& log) {
+// Return: 0 = ok, 1 = not well-formed (tinyxml2's LoadFile would fail: mismatched or unclosed elements, duplicate
+// attribute names, unquoted values, no element at all), 2 = well-formed but no <Scene> root.
+static int parse_scene_xml(const std::string& text, std::vector<XmlElem>& out, std::string& log) {
     size_t i = 0, n = text.size();
     bool in_scene = false, saw_scene = false;
     int depth = 0;
+    std::vector<std::string> open_names;
+    size_t n_elements = 0;
     while (i < n) {
         if (text[i] != '<') {
             ++i;
             continue;
         }
+        n_elements++;  // any node: only a document without a single one is "empty" for tinyxml2
         if (text.compare(i, 4, "<!--") == 0) {
             size_t e = text.find("-->", i + 4);
-            if (e == std::string::npos) return false;
+            if (e == std::string::npos) return 1;
             i = e + 3;
             continue;
         }
         if (text.compare(i, 2, "<?") == 0) {
             size_t e = text.find("?>", i + 2);
-            if (e == std::string::npos) return false;
+            if (e == std::string::npos) return 1;
             i = e + 2;
             continue;
         }
-        if (text[i + 1] == '/') {
+        if (text.compare(i, 2, "<!") == 0) {  // DOCTYPE / CDATA: skipped
             size_t e = text.find('>', i);
-            if (e == std::string::npos) return false;
+            if (e == std::string::npos) return 1;
+            i = e + 1;
+            continue;
+        }
+        if (i + 1 < n && text[i + 1] == '/') {
+            size_t e = text.find('>', i);
+            if (e == std::string::npos) return 1;
             std::string nm = text.substr(i + 2, e - i - 2);
             while (!nm.empty() && isspace((unsigned char)nm.back())) nm.pop_back();
+            if (open_names.empty() || open_names.back() != nm) return 1;
+            open_names.pop_back();
             depth--;
             if (nm == "Scene" && depth == 0) in_scene = false;
             i = e + 1;
@@ -664,7 +677,7 @@ static bool parse_scene_xml(const std::string& text, std::vector<XmlElem>& out, 
         bool selfclose = false;
         while (j < n) {
             while (j < n && isspace((unsigned char)text[j])) ++j;
-            if (j >= n) return false;
+            if (j >= n) return 1;
             if (text[j] == '/') {
                 selfclose = true;
                 ++j;
@@ -675,15 +688,16 @@ static bool parse_scene_xml(const std::string& text, std::vector<XmlElem>& out, 
                 break;
             }
             size_t k = j;
-            while (k < n && text[k] != '=' && !isspace((unsigned char)text[k])) ++k;
+            while (k < n && text[k] != '=' && text[k] != '>' && text[k] != '/' && !isspace((unsigned char)text[k])) ++k;
             std::string key = text.substr(j, k - j);
-            while (k < n && text[k] != '=') ++k;
+            while (k < n && isspace((unsigned char)text[k])) ++k;
+            if (k >= n || text[k] != '=' || key.empty()) return 1;  // an attribute needs ="value"
             ++k;
             while (k < n && isspace((unsigned char)text[k])) ++k;
-            if (k >= n || (text[k] != '"' && text[k] != '\'')) return false;
+            if (k >= n || (text[k] != '"' && text[k] != '\'')) return 1;
             char qc = text[k];
             size_t e = text.find(qc, k + 1);
-            if (e == std::string::npos) return false;
+            if (e == std::string::npos) return 1;
             std::string val = text.substr(k + 1, e - k - 1);
             // the five predefined entities
             std::string dec;
@@ -697,9 +711,13 @@ static bool parse_scene_xml(const std::string& text, std::vector<XmlElem>& out, 
                 }
                 dec += val[p];
             }
+            for (const auto& kv : el.attrs)
+                if (kv.first == key) return 1;
             el.attrs.emplace_back(key, dec);
             j = e + 1;
         }
+        if (el.name.empty()) return 1;
+        if (!selfclose) open_names.push_back(el.name);
         if (depth == 0 && el.name == "Scene" && !saw_scene) {
             saw_scene = true;
             in_scene = !selfclose;
@@ -709,11 +727,12 @@ static bool parse_scene_xml(const std::string& text, std::vector<XmlElem>& out, 
         if (!selfclose) depth++;
         i = j;
     }
+    if (!open_names.empty() || n_elements == 0) return 1;
     if (!saw_scene) {
         log += "No <Scene> root.\n";
-        return false;
+        return 2;
     }
-    return true;
+    return 0;
 }
 
 static std::string dirname_of(const std::string& p) {
@@ -747,12 +766,16 @@ static bool load_scene_xml(const std::string& path, const std::string& asset_roo
     fclose(f);
     std::vector<XmlElem> elems;
     std::string xlog;
-    bool ok = parse_scene_xml(text, elems, xlog);
+    const int parsed = parse_scene_xml(text, elems, xlog);
+    if (parsed == 1) {
+        sc.log += "Failed to load scene XML: " + path + "\n";
+        return false;  // LoadFile fails: SceneLoader.cpp:77-80, scene left as-is
+    }
     sc.prims.clear();  // SceneLoader.cpp:82
     sc.nodes.clear();
     sc.primIdx.clear();
     sc.log += xlog;
-    if (!ok) return false;
+    if (parsed != 0) return false;
     for (const XmlElem& e : elems) {
         if (e.name == "Sphere") {  // SceneLoader.cpp:92-106
             Primitive p;

@@ -333,3 +333,69 @@ def test_random_xml_formatting_matches_tinyxml2(ref, tmp_path):
         assert mats[i, 0, :3].tolist() == alb and mats[i, 1, :3].tolist() == emi, i
         assert mats[i, 0, 3] == np.float32(mtype) and mats[i, 1, 3] == np.float32(power), i
     ref.ref_xml_close(h)
+
+
+MALFORMED = {
+    "unclosed child": '<Scene><Sphere position="1,2,3"></Scene>',
+    "no scene close": '<Scene><Sphere position="1,2,3"/>',
+    "unquoted attr": '<Scene><Sphere position=1,2,3/></Scene>',
+    "truncated tag": '<Scene><Sphere position="1,2,3"/',
+    "mismatched": '<Scene><Sphere position="1,2,3"></Mesh></Scene>',
+    "dup attr": '<Scene><Sphere position="1,2,3" position="4,5,6"/></Scene>',
+    "attr no value": '<Scene><Sphere position/></Scene>',
+    "empty": '',
+    "blank": '  \n\t ',
+}
+WELLFORMED = {
+    "text content": ('<Scene>hello<Sphere position="1,2,3"/>world</Scene>', 1),
+    "nested child": ('<Scene><Group><Sphere position="1,2,3"/></Group><Sphere position="4,5,6"/></Scene>', 1),
+    "two roots": ('<Scene><Sphere position="1,2,3"/></Scene><Scene><Sphere position="4,5,6"/></Scene>', 1),
+    "bom+decl": ('﻿<?xml version="1.0"?><Scene><Sphere position="1,2,3"/></Scene>', 1),
+    "cdata": ('<Scene><![CDATA[ <Sphere position="9,9,9"/> ]]><Sphere position="1,2,3"/></Scene>', 1),
+    "end tag space": ('<Scene ><Sphere position="1,2,3" ></Sphere ></Scene >', 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MALFORMED))
+def test_malformed_xml_is_rejected_like_tinyxml2_and_leaves_the_scene_alone(ref, tmp_path, name):
+    """tinyxml2's LoadFile fails on these; the reference then returns before scene->clear() (SceneLoader.cpp:76-80)."""
+    p = tmp_path / "bad.xml"
+    p.write_text(MALFORMED[name], encoding="utf-8")
+    n = C.c_int64()
+    assert not ref.ref_xml_open(str(p).encode(), C.byref(n)) and n.value == -1
+    hs = host.Scene()
+    hs.addSphere((0, 0, 0), 1.0)
+    st, log = host.SceneLoader.LoadSceneFromXML(str(p), hs)
+    assert st in (1, 3) and "Failed to load scene XML" in log and hs.getPrimitiveCount() == 1
+    osn = ob.OracleScene()
+    osn.add_sphere((0, 0, 0), 1.0) if hasattr(osn, "add_sphere") else None
+    assert osn.load_xml(str(p)) != 0
+
+
+def test_comment_only_document_has_no_scene_root(ref, tmp_path):
+    p = tmp_path / "c.xml"
+    p.write_text("<!-- nothing here -->")
+    n = C.c_int64()
+    assert not ref.ref_xml_open(str(p).encode(), C.byref(n)) and n.value == -2      # LoadFile ok, no <Scene>
+    hs = host.Scene()
+    hs.addSphere((0, 0, 0), 1.0)
+    st, log = host.SceneLoader.LoadSceneFromXML(str(p), hs)
+    assert st == 2 and "No <Scene> root." in log and hs.getPrimitiveCount() == 0     # cleared, SceneLoader.cpp:82-88
+
+
+@pytest.mark.parametrize("name", sorted(WELLFORMED))
+def test_odd_but_wellformed_xml_is_accepted_like_tinyxml2(ref, tmp_path, name):
+    text, spheres = WELLFORMED[name]
+    p = tmp_path / "ok.xml"
+    p.write_text(text, encoding="utf-8")
+    n = C.c_int64()
+    h = ref.ref_xml_open(str(p).encode(), C.byref(n))
+    assert h
+    direct = sum(1 for i in range(n.value) if ref.ref_xml_name(h, i) == b"Sphere")
+    ref.ref_xml_close(h)
+    assert direct == spheres
+    hs = host.Scene()
+    st, _ = host.SceneLoader.LoadSceneFromXML(str(p), hs)
+    assert st == 0 and hs.getPrimitiveCount() == spheres
+    osn = ob.OracleScene()
+    assert osn.load_xml(str(p)) == 0 and osn.prim_count == spheres
