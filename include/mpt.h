@@ -58,7 +58,12 @@ enum { MPT_BSDF_LAMBERT = 0, /* what rayColor executes (PathTracing.h:251-255)  
        MPT_BSDF_SCATTER = 1 }; /* + mirror / dielectric per Scatter.h:22-43 (dead code in the ref)    */
 enum { MPT_PIPE_WAVEFRONT = 0,  /* global SoA ray queues + wave64 ballot compaction, one kernel/bounce */
        MPT_PIPE_MEGAKERNEL = 1, /* one thread per path, whole bounce loop in registers                */
-       MPT_PIPE_WAVELOCAL = 2 };/* persistent waves, wave-private ray rings + ballot compaction        */
+       MPT_PIPE_WAVELOCAL = 2,  /* persistent waves, wave-private ray rings + ballot compaction; pipelines 0-2 walk
+                                   the BVH in the reference's own order (PathTracing.h:188-193)                      */
+       MPT_PIPE_ORDERED = 3 };  /* the same wave-local wavefront over the product's own 4-wide BVH, closest child
+                                   first, with the reference-order walk for the rays whose answer could depend on the
+                                   order (same image bit for bit; falls back to pipeline 2 when a scene's child boxes
+                                   are not nested in their parents' or it has more than 16 spheres)                  */
 
 typedef struct mpt_render_params {
     int32_t rng_mode;        /* MPT_RNG_*                                                             */
@@ -91,6 +96,9 @@ typedef struct mpt_stats {   /* cumulative since mpt_reset_stats                
     uint64_t wave_node_iters;   /* box-test loop trips                                                        */
     uint64_t wave_prim_iters;   /* primitive-test loop trips                                                  */
     uint64_t wave_leaf_phases;  /* leaf phases entered                                                        */
+    /* MPT_PIPE_ORDERED only */
+    uint64_t exact_retraces;    /* rays handed to the reference-order walk (ties, inconsistent winners, ...)          */
+    uint64_t tree_parked;       /* rays parked for a full-width tree step after the top test                          */
 } mpt_stats;
 
 /* Device selection / lifetime.  Replaces MTL::CreateSystemDefaultDevice + Renderer::Renderer /
@@ -160,6 +168,18 @@ int mpt_synchronize(mpt_ctx* ctx);
  * normal (3 floats, flipped to face the ray), front-face flag.                                       */
 int mpt_trace_rays(mpt_ctx* ctx, const float* origins, const float* directions, uint64_t n_rays, float* t_out,
                    int32_t* prim_out, float* normal_out, int32_t* front_out);
+
+/* The same through the closest-first walk of MPT_PIPE_ORDERED (must return exactly what mpt_trace_rays returns).
+ * flags_out (host, one uint32 per ray): 0 = answered by the closest-first walk; otherwise the ray was re-traced in
+ * reference order because of 1 a (nearly) zero / non-finite direction component or a far origin, 2 a tie between two
+ * primitives, 4 a winner in front of its own reference leaf box, 8 stack overflow.                                   */
+int mpt_trace_rays_ordered(mpt_ctx* ctx, const float* origins, const float* directions, uint64_t n_rays, float* t_out,
+                           int32_t* prim_out, float* normal_out, int32_t* front_out, uint32_t* flags_out);
+
+/* Shape of the product's own acceleration structure for the uploaded scene: out[0] = 1 if MPT_PIPE_ORDERED can be used,
+ * [1] own 4-wide nodes, [2] its depth, [3] nodes staged in LDS, [4] spheres on the always list, [5] reference leaves,
+ * [6] primitives staged in LDS, [7] reserved.                                                                          */
+int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 
 /* RNG known-answer hooks evaluated ON THE DEVICE (Random.h:6-16 and the philox / sincos spec).      */
 int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* hash_out, float* float_out);

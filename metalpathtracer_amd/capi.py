@@ -13,8 +13,9 @@ LIB_PATH = os.environ.get("MPT_LIB") or os.path.join(_PKG, "lib", "libmpt_hip.so
 
 RNG_LITERAL, RNG_PHILOX = 0, 1
 BSDF_LAMBERT, BSDF_SCATTER = 0, 1
-PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL = 0, 1, 2
-DEFAULT_PIPELINE = PIPE_WAVELOCAL  # fastest measured pipeline on MI355X (DESIGN.md "Pipelines, measured")
+PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL, PIPE_ORDERED = 0, 1, 2, 3
+REFERENCE_ORDER_PIPELINES = (PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL)  # walk the BVH in the reference's own order
+DEFAULT_PIPELINE = PIPE_ORDERED  # fastest measured pipeline on MI355X (DESIGN.md "Pipelines, measured")
 FLAG_COUNT_WORK = 1
 
 STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT_ERR_HIP",
@@ -25,7 +26,7 @@ SYMBOLS = (
     "mpt_create", "mpt_destroy", "mpt_last_error", "mpt_status_string", "mpt_upload_scene", "mpt_set_uniforms",
     "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
     "mpt_read_frame", "mpt_read_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
-    "mpt_trace_rays", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
+    "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
 )
 
 
@@ -71,6 +72,7 @@ class Stats(C.Structure):
         ("prim_tests", C.c_uint64), ("iterations", C.c_uint64),
         ("trace_kernel_ms", C.c_double), ("total_ms", C.c_double), ("trace_launches", C.c_uint64),
         ("wave_node_iters", C.c_uint64), ("wave_prim_iters", C.c_uint64), ("wave_leaf_phases", C.c_uint64),
+        ("exact_retraces", C.c_uint64), ("tree_parked", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -114,6 +116,8 @@ def load():
     L.mpt_stream.restype = vp
     L.mpt_synchronize.argtypes = [vp]
     L.mpt_trace_rays.argtypes = [vp, fp, fp, C.c_uint64, fp, ip, fp, ip]
+    L.mpt_trace_rays_ordered.argtypes = [vp, fp, fp, C.c_uint64, fp, ip, fp, ip, up]
+    L.mpt_accel_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.mpt_kat_pcg.argtypes = [vp, up, C.c_uint64, up, fp]
     L.mpt_kat_philox.argtypes = [vp, up, up, C.c_uint64, up]
     L.mpt_kat_sincos.argtypes = [vp, fp, C.c_uint64, fp, fp]
@@ -246,6 +250,26 @@ class Context:
         self._chk(self.L.mpt_trace_rays(self.h, _fp(o), _fp(d), n, _fp(t), _ip(prim), _fp(nrm), _ip(front)),
                   "mpt_trace_rays")
         return t, prim, nrm, front
+
+    def trace_rays_ordered(self, origins, directions):
+        """Closest hit through the closest-first walk of PIPE_ORDERED; also returns the per-ray re-trace flags."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n, np.float32)
+        prim = np.empty(n, np.int32)
+        nrm = np.empty((n, 3), np.float32)
+        front = np.empty(n, np.int32)
+        flags = np.empty(n, np.uint32)
+        self._chk(self.L.mpt_trace_rays_ordered(self.h, _fp(o), _fp(d), n, _fp(t), _ip(prim), _fp(nrm), _ip(front),
+                                                _up(flags)), "mpt_trace_rays_ordered")
+        return t, prim, nrm, front, flags
+
+    def accel_info(self):
+        out = (C.c_uint64 * 8)()
+        self._chk(self.L.mpt_accel_info(self.h, out), "mpt_accel_info")
+        keys = ("ordered_ok", "nodes", "depth", "lds_nodes", "always_spheres", "reference_leaves", "lds_prims")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def kat_pcg(self, seeds):
         s = np.ascontiguousarray(seeds, np.uint32)

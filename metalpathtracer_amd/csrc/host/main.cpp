@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     std::memset(&prm, 0, sizeof prm);
     prm.rng_mode = MPT_RNG_PHILOX;
     prm.shard_count = 1;
-    prm.pipeline = MPT_PIPE_WAVELOCAL;
+    prm.pipeline = MPT_PIPE_ORDERED;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* {
@@ -69,7 +69,8 @@ int main(int argc, char** argv) {
         else if (a == "--pipeline") {
             const char* v = next();
             prm.pipeline = std::strcmp(v, "megakernel") == 0 ? MPT_PIPE_MEGAKERNEL
-                           : std::strcmp(v, "wavefront") == 0 ? MPT_PIPE_WAVEFRONT : MPT_PIPE_WAVELOCAL;
+                           : std::strcmp(v, "wavefront") == 0 ? MPT_PIPE_WAVEFRONT
+                           : std::strcmp(v, "wavelocal") == 0 ? MPT_PIPE_WAVELOCAL : MPT_PIPE_ORDERED;
         }
         else {
             usage();

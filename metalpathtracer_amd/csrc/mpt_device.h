@@ -107,8 +107,8 @@ typedef const __attribute__((address_space(3))) v4f* LdsNodes;
 //   index >= n_nodes terminates.  Nodes are stored breadth-first so that the first n_lds nodes (top
 //   of the tree) can be staged in LDS.
 // Device primitive, 48 bytes, stored in leaf order:
-//   triangle: (v0.xyz, 1.0f) (e1.xyz, bits(mat)) (e2.xyz, bits(orig id))     e1 = v1-v0, e2 = v2-v0
-//   sphere:   (c.xyz,  0.0f) (r,0,0, bits(mat)) (0,0,0,  bits(orig id))
+//   triangle: (v0.xyz, bits(leaf << 1 | 1)) (e1.xyz, bits(mat)) (e2.xyz, bits(orig id))     e1 = v1-v0, e2 = v2-v0
+//   sphere:   (c.xyz,  bits(leaf << 1))     (r, bits(own index),0, bits(mat)) (0,0,0,  bits(orig id))
 struct SceneDev {
     const float4* nodes;
     const float4* prims;
@@ -119,7 +119,13 @@ struct SceneDev {
     uint32_t n_lds_mats;   // materials [0, n_lds_mats) are also in LDS, behind the primitives
     uint32_t n_prims;
     uint32_t n_mats;
+    uint32_t lds_prim_off;  // where the primitive / material images start in the workgroup's LDS (in float4 units):
+    uint32_t lds_mat_off;   // the reference-order kernels stage 2 float4 per node in front of them, k_ordered 7
 };
+// Primitive record word p0.w: (reference leaf id << 1) | type (0 sphere, 1 triangle).  The leaf id is what the ordered
+// walk's final check needs (mpt_ordered.h); leaves are numbered in the reference's visit order.
+__device__ __forceinline__ int prim_type(float4 p0) { return __float_as_int(p0.w) & 1; }
+__device__ __forceinline__ uint32_t prim_ref_leaf(float4 p0) { return (uint32_t)__float_as_int(p0.w) >> 1; }
 
 // true in exactly one lane of the currently active lanes (used to count wave-level loop trips)
 __device__ __forceinline__ bool first_active_lane() {
@@ -167,7 +173,7 @@ struct Prim3 {
 __device__ __forceinline__ Prim3 load_prim(const SceneDev& sc, LdsNodes lds, uint32_t i) {
     Prim3 r;
     if (i < sc.n_lds_prims) {
-        const LdsNodes q = lds + 2u * sc.n_lds_nodes + 3u * i;
+        const LdsNodes q = lds + sc.lds_prim_off + 3u * i;
         const v4f a = q[0], b = q[1], c = q[2];
         r.p0 = make_float4(a.x, a.y, a.z, a.w);
         r.p1 = make_float4(b.x, b.y, b.z, b.w);
@@ -193,7 +199,7 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
             wc.prim_tests++;
             if (first_active_lane()) wc.prim_iters++;
         }
-        const int ptype = (int)p0.w;
+        const int ptype = prim_type(p0);
         if (ptype == 1) {  // PathTracing.h:143-176 Moeller-Trumbore, two-sided
             F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
             F3 h = cross3(d, e2);
@@ -368,7 +374,7 @@ __device__ __forceinline__ HitInfo finish_hit(const SceneDev& sc, LdsNodes lds, 
     const Prim3 pr = load_prim(sc, lds, (uint32_t)prim);
     const float4 p0 = pr.p0, p1 = pr.p1, p2 = pr.p2;
     h.point = o + t * d;
-    if ((int)p0.w == 1) {
+    if (prim_type(p0) == 1) {
         h.normal = normalize3(cross3(f3(p1.x, p1.y, p1.z), f3(p2.x, p2.y, p2.z)));
     } else {
         h.normal = normalize3(h.point - f3(p0.x, p0.y, p0.z));
@@ -460,7 +466,7 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, LdsNodes lds, c
     if ((uint32_t)h.orig_id >= sp.primitive_count) return false;  // PathTracing.h:234-236
     float4 m0, m1;
     if ((uint32_t)h.mat < sc.n_lds_mats) {  // the de-duplicated material table is tiny: served from LDS
-        const LdsNodes q = lds + 2u * sc.n_lds_nodes + 3u * sc.n_lds_prims + 2u * (uint32_t)h.mat;
+        const LdsNodes q = lds + sc.lds_mat_off + 2u * (uint32_t)h.mat;
         const v4f a = q[0], b = q[1];
         m0 = make_float4(a.x, a.y, a.z, a.w);
         m1 = make_float4(b.x, b.y, b.z, b.w);

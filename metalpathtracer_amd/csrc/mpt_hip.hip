@@ -20,9 +20,11 @@
 #include <vector>
 
 #include "mpt.h"
+#include "mpt_accel.h"
 #include "mpt_device.h"
 
 #include "mpt_kernels.h"
+#include "mpt_ordered.h"
 
 // =====================================================================================================
 // host side of the C ABI
@@ -62,6 +64,8 @@ struct Lane {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_timed;  // kernel-event pairs to read at collection
     WaveRings ring = {};         // wave-local pipeline: MPT_WL_LEVELS rings of MPT_WL_RING records per wave
     size_t ring_waves = 0;
+    uint2* d_ot_spill = nullptr; // closest-first pipeline: stack entries beyond the LDS part, per wave
+    size_t ot_spill_waves = 0;
     bool in_flight = false;      // enqueued by mpt_render_async, not yet collected
     bool timed = false;
 };
@@ -81,6 +85,16 @@ struct mpt_ctx {
     float4* d_mats = nullptr;
     uint32_t n_nodes = 0, n_prims = 0, n_mats = 0, n_lds_nodes = 0, n_lds_prims = 0;
     bool have_scene = false;
+    // the product's own tree (mpt_accel.h) for the closest-first pipeline; it shares d_prims with the threaded tree
+    float4* d_acc_nodes = nullptr;
+    float4* d_refleaf = nullptr;
+    float4* d_always = nullptr;
+    uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, ot_lds_nodes = 0, ot_lds_prims = 0;
+    uint32_t ot_stack_depth = 8;     // LDS stack entries per lane (MPT_OT_STACK); deeper entries spill to global memory
+    uint32_t ot_walk_now_min = 24;   // a primary / fresh-ray step walks the tree at once when this many lanes need it
+    float tri_extent = 0.0f, acc_eps_abs = 0.0f;
+    bool acc_ok = false;             // the closest-first pipeline may be used for this scene
+    std::string acc_why;
     // uniforms / size
     mpt_uniforms u;
     bool have_uniforms = false;
@@ -122,6 +136,8 @@ static const void* mega_kernel(bool count, bool all_lds) {
     if (count) return all_lds ? (const void*)k_megakernel<true, true> : (const void*)k_megakernel<true, false>;
     return all_lds ? (const void*)k_megakernel<false, true> : (const void*)k_megakernel<false, false>;
 }
+
+static const void* ordered_kernel(bool count) { return count ? (const void*)k_ordered<true> : (const void*)k_ordered<false>; }
 
 static const void* wavelocal_kernel(bool count, bool all_lds) {
     if (count) return all_lds ? (const void*)k_wavelocal<true, true> : (const void*)k_wavelocal<true, false>;
@@ -233,6 +249,8 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_WL_MIN")) && atoi(e) >= 64) ctx->wl_min = (uint32_t)atoi(e) & ~63u;
     if ((e = getenv("MPT_TILE_ORDER"))) ctx->tile_order_mode = atoi(e);
     if ((e = getenv("MPT_WL_DIV")) && atoi(e) >= 1) ctx->wl_div = (uint32_t)atoi(e);
+    if ((e = getenv("MPT_OT_STACK")) && atoi(e) >= 2 && atoi(e) <= 12) ctx->ot_stack_depth = (uint32_t)atoi(e);
+    if ((e = getenv("MPT_OT_WALK_NOW")) && atoi(e) >= 1 && atoi(e) <= 65) ctx->ot_walk_now_min = (uint32_t)atoi(e);
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 0;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
@@ -242,6 +260,8 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
             hipFuncSetAttribute(mega_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute(wavelocal_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
+    for (int c = 0; c < 2; ++c) hipFuncSetAttribute(ordered_kernel(c), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_trace_rays_ordered, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return MPT_OK;
@@ -266,6 +286,9 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_nodes);
     hipFree(ctx->d_prims);
     hipFree(ctx->d_mats);
+    hipFree(ctx->d_acc_nodes);
+    hipFree(ctx->d_refleaf);
+    hipFree(ctx->d_always);
     hipFree(ctx->d_accum[0]);
     hipFree(ctx->d_accum[1]);
     hipFree(ctx->d_sum_own);
@@ -280,6 +303,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
         hipFree(L.ring.tl);
         hipFree(L.ring.ia);
         hipFree(L.ring.tv);
+        hipFree(L.d_ot_spill);
         free_queues(L);
         if (L.h_done) hipHostFree(L.h_done);
         if (L.h_desc) hipHostFree(L.h_desc);
@@ -373,6 +397,21 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     }
     const uint32_t NV = (uint32_t)order.size();  // reachable nodes
 
+    // 1b. every child box must lie inside its parent's box: then the reference's walk equals a scan over the leaves in
+    //     visit order (mpt_ordered.h) and the closest-first pipeline may be used; otherwise only the reference-order ones.
+    bool nested = true;
+    for (uint32_t pos = 0; pos < NV && nested; ++pos) {
+        const float* n = bvh + 8 * (size_t)order[pos];
+        if (bits_to_int(n[7]) > 0) continue;
+        const uint32_t kids[2] = {pos + 1, pos + 1 < NV ? sub_end[pos + 1] : NV};
+        for (uint32_t k : kids) {
+            if (k >= NV) continue;
+            const float* c = bvh + 8 * (size_t)order[k];
+            for (int a = 0; a < 3; ++a)
+                if (!(c[a] >= n[a] && c[4 + a] <= n[4 + a])) nested = false;
+        }
+    }
+
     // 2. leaves: gather primitives into leaf order; split leaves of more than 16 primitives into a chain.
     //    Device node list in VISIT order first (dn), then permuted breadth-first.
     struct DNode {
@@ -380,6 +419,7 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         bool leaf;
         uint32_t first, count;   // leaf
         uint32_t hit, miss;      // links as indices into dn (visit order); N_total = end
+        uint32_t ref_leaf;       // leaf: number of the reference leaf it came from (visit order)
     };
     std::vector<DNode> dn;
     dn.reserve(NV + 16);
@@ -387,6 +427,7 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     std::vector<float> dprims;
     dprims.reserve((size_t)P * 12);
     std::vector<float> mat_table;
+    std::vector<float> refleaf;  // 8 floats per reference leaf: (bmin, 0) (bmax, 0)
     std::map<std::vector<uint32_t>, uint32_t> mat_lookup;
     auto mat_index = [&](uint32_t pid) -> uint32_t {
         std::vector<uint32_t> key(8);
@@ -398,6 +439,8 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         mat_lookup.emplace(std::move(key), id);
         return id;
     };
+    uint32_t n_spheres = 0;
+    float tri_extent = 0.0f;  // largest |coordinate| of a triangle vertex
     // first pass: create dn entries; a long leaf becomes ceil(count/16) chained nodes
     for (uint32_t pos = 0; pos < NV; ++pos) {
         const float* n = bvh + 8 * (size_t)order[pos];
@@ -407,9 +450,13 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         memcpy(d.bmin, n, 12);
         memcpy(d.bmax, n + 4, 12);
         d.hit = d.miss = 0;
+        d.ref_leaf = 0;
         if (count > 0) {
             int first = bits_to_int(n[3]);
             d.leaf = true;
+            d.ref_leaf = (uint32_t)(refleaf.size() / 8);
+            const float rl[8] = {n[0], n[1], n[2], 0.0f, n[4], n[5], n[6], 0.0f};
+            refleaf.insert(refleaf.end(), rl, rl + 8);
             for (int k0 = 0; k0 < count; k0 += 16) {
                 d.first = (uint32_t)(dprims.size() / 12);
                 d.count = (uint32_t)std::min(16, count - k0);
@@ -421,14 +468,18 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
                     int type = (int)p[3];
                     uint32_t m = mat_index((uint32_t)pid);
                     if (type == 1) {  // triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (PathTracing.h:149-150)
-                        rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2]; rec[3] = 1.0f;
+                        rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2];
                         rec[4] = p[4] - p[0]; rec[5] = p[5] - p[1]; rec[6] = p[6] - p[2];
                         rec[8] = p[8] - p[0]; rec[9] = p[9] - p[1]; rec[10] = p[10] - p[2];
-                    } else {
-                        rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2]; rec[3] = p[3];
-                        rec[4] = p[4]; rec[5] = 0; rec[6] = 0;
+                        for (int q = 0; q < 11; ++q)
+                            if ((q & 3) != 3 && std::isfinite(p[q])) tri_extent = std::max(tri_extent, fabsf(p[q]));
+                    } else {  // sphere; anything that is neither is never hit (PathTracing.h:120,143) — kept as a sphere of radius NaN
+                        rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2];
+                        rec[4] = type == 0 ? p[4] : NAN; rec[5] = 0; rec[6] = 0;
                         rec[8] = 0; rec[9] = 0; rec[10] = 0;
+                        n_spheres++;
                     }
+                    rec[3] = int_to_bits((int)((d.ref_leaf << 1) | (type == 1 ? 1u : 0u)));
                     rec[7] = int_to_bits((int)m);
                     rec[11] = int_to_bits(pid);
                     dprims.insert(dprims.end(), rec, rec + 12);
@@ -454,7 +505,93 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
             dn[a].miss = pos_to_dn[sub_end[pos]];
         }
     }
-    // 3. breadth-first permutation (top of the tree first -> LDS).  Depth of a dn node = depth in the tree.
+
+    // 3. the product's own tree over the leaves (mpt_accel.h): spheres go to the always list (their t has no usable
+    //    error bound: the r = 10^4 ground sphere), every leaf that holds triangles becomes an item whose box contains
+    //    the reference leaf box — or, for the triangles that share a leaf with a sphere, a tight box of their own.
+    const bool use_always = n_spheres <= MPT_ACCEL_MAX_ALWAYS;
+    const float pad = std::max(tri_extent, 1e-6f) * 6.103515625e-05f;  // 2^-14: covers the rcp / fma slab arithmetic
+    std::vector<mpt_accel::Item> items;
+    std::vector<uint32_t> item_dn;  // item -> dn index
+    std::vector<uint32_t> sphere_only_dn;
+    std::vector<float> always;
+    for (uint32_t i = 0; i < ND; ++i) {
+        const DNode& d = dn[i];
+        if (!d.leaf) continue;
+        mpt_accel::Box tb = mpt_accel::empty_box();
+        uint32_t ntri = 0, nsph = 0;
+        for (uint32_t k = 0; k < d.count; ++k) {
+            const float* r = dprims.data() + (size_t)(d.first + k) * 12;
+            if (bits_to_int(r[3]) & 1) {
+                ntri++;
+                const float v[3][3] = {{r[0], r[1], r[2]}, {r[0] + r[4], r[1] + r[5], r[2] + r[6]}, {r[0] + r[8], r[1] + r[9], r[2] + r[10]}};
+                for (auto& q : v) {
+                    mpt_accel::Box c;
+                    memcpy(c.lo, q, 12);
+                    memcpy(c.hi, q, 12);
+                    mpt_accel::grow(tb, c);
+                }
+            } else {
+                nsph++;
+            }
+        }
+        if (ntri == 0 && use_always) {
+            sphere_only_dn.push_back(i);
+            continue;
+        }
+        mpt_accel::Item it;
+        memcpy(it.box.lo, d.bmin, 12);
+        memcpy(it.box.hi, d.bmax, 12);
+        if (nsph != 0 && use_always) {  // a sphere's leaf-mates: v0 + e is not exactly the vertex, hence the generous margin
+            float ext = 0.0f;
+            for (int a = 0; a < 3; ++a) ext = std::max(ext, tb.hi[a] - tb.lo[a]);
+            for (int a = 0; a < 3; ++a) {
+                it.box.lo[a] = std::max(d.bmin[a], tb.lo[a] - 0.05f * ext - pad);
+                it.box.hi[a] = std::min(d.bmax[a], tb.hi[a] + 0.05f * ext + pad);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            it.box.lo[a] -= pad;
+            it.box.hi[a] += pad;
+        }
+        it.count = d.count;
+        it.key = i;
+        items.push_back(it);
+        item_dn.push_back(i);
+    }
+    const mpt_accel::Topology topo = mpt_accel::build_topology(items);
+
+    // 4. ONE primitive array for both structures: leaves without an item (spheres only) first — the reference-order
+    //    kernels test them for almost every ray, so they belong to the LDS-staged prefix — then the items in the
+    //    breadth-first order of the own tree (shallow leaves first).
+    std::vector<uint32_t> first_of(items.size(), 0);
+    {
+        std::vector<float> ordered(dprims.size());
+        uint32_t at = 0;
+        auto place = [&](DNode& d) {
+            memcpy(ordered.data() + (size_t)at * 12, dprims.data() + (size_t)d.first * 12, (size_t)d.count * 48);
+            d.first = at;
+            at += d.count;
+        };
+        for (uint32_t i : sphere_only_dn) place(dn[i]);
+        for (uint32_t it : topo.item_order) {
+            place(dn[item_dn[it]]);
+            first_of[it] = dn[item_dn[it]].first;
+        }
+        dprims.swap(ordered);
+    }
+    const std::vector<float> acc_nodes = mpt_accel::emit(topo, items, first_of);
+    if (use_always)
+        for (size_t i = 0; i < dprims.size() / 12; ++i) {
+            const float* r = dprims.data() + i * 12;
+            if (bits_to_int(r[3]) & 1) continue;
+            float rec[12];
+            memcpy(rec, r, 48);
+            rec[5] = int_to_bits((int)i);  // own position in the primitive array = what the walk reports as the winner
+            always.insert(always.end(), rec, rec + 12);
+        }
+
+    // 5. reference-order structure: breadth-first permutation of the threaded nodes (top of the tree first -> LDS).
     std::vector<uint32_t> depth(ND, 0);
     {
         // depth by walking positions: children of internal at pos are pos+1 (right) and sub_end[pos+1] (left)
@@ -479,20 +616,6 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     std::vector<uint32_t> inv(ND + 1);
     for (uint32_t i = 0; i < ND; ++i) inv[perm[i]] = i;
     inv[ND] = ND;  // terminator
-    // primitives follow the same breadth-first order as the nodes: the leaves next to the root come first, so a
-    // prefix of the primitive array (the part staged in LDS) holds the most frequently tested primitives
-    {
-        std::vector<float> ordered(dprims.size());
-        uint32_t at = 0;
-        for (uint32_t i = 0; i < ND; ++i) {
-            DNode& d = dn[perm[i]];
-            if (!d.leaf) continue;
-            memcpy(ordered.data() + (size_t)at * 12, dprims.data() + (size_t)d.first * 12, (size_t)d.count * 48);
-            d.first = at;
-            at += d.count;
-        }
-        dprims.swap(ordered);
-    }
     std::vector<float> dnodes((size_t)ND * 8);
     for (uint32_t i = 0; i < ND; ++i) {
         const DNode& d = dn[perm[i]];
@@ -511,20 +634,36 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     hipFree(ctx->d_nodes);
     hipFree(ctx->d_prims);
     hipFree(ctx->d_mats);
-    ctx->d_nodes = ctx->d_prims = ctx->d_mats = nullptr;
+    hipFree(ctx->d_acc_nodes);
+    hipFree(ctx->d_refleaf);
+    hipFree(ctx->d_always);
+    ctx->d_nodes = ctx->d_prims = ctx->d_mats = ctx->d_acc_nodes = ctx->d_refleaf = ctx->d_always = nullptr;
     ctx->have_scene = false;
-    HIPCHK(hipMalloc(&ctx->d_nodes, dnodes.size() * 4));
-    HIPCHK(hipMalloc(&ctx->d_prims, std::max<size_t>(dprims.size(), 12) * 4));
-    HIPCHK(hipMalloc(&ctx->d_mats, std::max<size_t>(mat_table.size(), 8) * 4));
-    HIPCHK(hipMemcpy(ctx->d_nodes, dnodes.data(), dnodes.size() * 4, hipMemcpyHostToDevice));
-    if (!dprims.empty()) HIPCHK(hipMemcpy(ctx->d_prims, dprims.data(), dprims.size() * 4, hipMemcpyHostToDevice));
-    if (!mat_table.empty()) HIPCHK(hipMemcpy(ctx->d_mats, mat_table.data(), mat_table.size() * 4, hipMemcpyHostToDevice));
+    auto up = [&](float4** dst, const std::vector<float>& v, size_t min_floats) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max(v.size(), min_floats) * 4);
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+    };
+    HIPCHK(up(&ctx->d_nodes, dnodes, 8));
+    HIPCHK(up(&ctx->d_prims, dprims, 12));
+    HIPCHK(up(&ctx->d_mats, mat_table, 8));
+    HIPCHK(up(&ctx->d_acc_nodes, acc_nodes, MPT_ACCEL_NODE_FLOATS));
+    HIPCHK(up(&ctx->d_refleaf, refleaf, 8));
+    HIPCHK(up(&ctx->d_always, always, 12));
     ctx->n_nodes = ND;
     ctx->n_prims = (uint32_t)(dprims.size() / 12);
     ctx->n_mats = (uint32_t)(mat_table.size() / 8);
-    // LDS image = top of the tree + primitives of the shallowest leaves.  When the whole tree fits, the rest of the
-    // budget goes to primitives; otherwise 6 KiB are reserved for them (the leaves next to the root are visited by
-    // almost every ray: on scene.xml the three spheres take 65 % of all primitive tests).
+    ctx->n_acc_nodes = (uint32_t)(acc_nodes.size() / MPT_ACCEL_NODE_FLOATS);
+    ctx->n_always = (uint32_t)(always.size() / 12);
+    ctx->n_ref_leaves = (uint32_t)(refleaf.size() / 8);
+    ctx->acc_depth = topo.depth;
+    ctx->tri_extent = tri_extent;
+    ctx->acc_eps_abs = tri_extent * 3.814697265625e-06f;  // 2^-18 of the largest triangle coordinate
+    ctx->acc_ok = nested && use_always;
+    ctx->acc_why = !nested ? "a child box is not inside its parent's box" : !use_always ? "more than 16 spheres" : "";
+    // LDS image of the reference-order kernels = top of the tree + primitives of the shallowest leaves.  When the whole
+    // tree fits, the rest of the budget goes to primitives; otherwise 6 KiB are reserved for them (the leaves next to the
+    // root are visited by almost every ray: on scene.xml the three spheres take 65 % of all primitive tests).
     {
         const size_t budget = ctx->lds_budget > MPT_LDS_EXTRA ? ctx->lds_budget - MPT_LDS_EXTRA : 0;
         const size_t all_nodes = (size_t)ND * 32, all_prims = dprims.size() / 12 * 48;
@@ -533,6 +672,18 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         prim_bytes -= prim_bytes % 48;
         ctx->n_lds_prims = (uint32_t)(prim_bytes / 48);
         ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ND, (budget - prim_bytes) / 32);
+    }
+    // LDS image of the closest-first kernel (one 1024-thread workgroup per CU): the stacks, then as many own nodes as
+    // fit (breadth-first prefix), the always list, and primitives with what is left (at least 4 KiB of them).
+    {
+        const size_t stacks = (size_t)MPT_OT_THREADS * ctx->ot_stack_depth * 8;
+        const size_t total = 160 * 1024 - MPT_LDS_EXTRA - stacks - (size_t)ctx->n_always * 48;
+        const size_t all_nodes = (size_t)ctx->n_acc_nodes * 112, all_prims = (size_t)ctx->n_prims * 48;
+        size_t prim_bytes = all_nodes <= total ? std::min(all_prims, total - all_nodes)
+                                               : std::min<size_t>(all_prims, std::min<size_t>(4 * 1024, total / 4));
+        prim_bytes -= prim_bytes % 48;
+        ctx->ot_lds_prims = (uint32_t)(prim_bytes / 48);
+        ctx->ot_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
     }
     ctx->have_scene = true;
     return MPT_OK;
@@ -645,7 +796,42 @@ static SceneDev scene_dev(const mpt_ctx* ctx) {
     s.n_lds_mats = std::min<uint32_t>(ctx->n_mats, MPT_LDS_MATS);
     s.n_prims = ctx->n_prims;
     s.n_mats = ctx->n_mats;
+    s.lds_prim_off = 2u * s.n_lds_nodes;
+    s.lds_mat_off = s.lds_prim_off + 3u * s.n_lds_prims;
     return s;
+}
+
+// The closest-first kernel's view: own nodes / always list / primitives / materials / stacks in LDS; the threaded
+// reference-order nodes stay in global memory (ring E and the test hook walk them from there).
+static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack_depth, SceneDev& s, AccelDev& a) {
+    s = scene_dev(ctx);
+    s.n_lds_nodes = 0;
+    s.n_lds_prims = ctx->ot_lds_prims;
+    a.nodes = ctx->d_acc_nodes;
+    a.refleaf = ctx->d_refleaf;
+    a.always = ctx->d_always;
+    a.spill = nullptr;
+    a.n_nodes = ctx->n_acc_nodes;
+    a.n_lds_nodes = ctx->ot_lds_nodes;
+    a.n_always = ctx->n_always;
+    a.lds_always_off = 7u * a.n_lds_nodes;
+    s.lds_prim_off = a.lds_always_off + 3u * a.n_always;
+    s.lds_mat_off = s.lds_prim_off + 3u * s.n_lds_prims;
+    const uint32_t image4 = s.lds_mat_off + 2u * s.n_lds_mats;
+    a.lds_stack_off = image4 * 16u;
+    a.stack_depth = stack_depth;
+    a.eps_abs = ctx->acc_eps_abs;
+    a.o_limit = ctx->tri_extent > 0.0f ? 64.0f * ctx->tri_extent : INFINITY;  // no triangles: no tree, nothing to bound
+    return (size_t)a.lds_stack_off + (size_t)threads * stack_depth * 8u;
+}
+static int ensure_spill(mpt_ctx* ctx, uint2** spill, size_t* have, size_t waves) {
+    if (waves <= *have) return MPT_OK;
+    hipFree(*spill);
+    *spill = nullptr;
+    *have = 0;
+    HIPCHK(hipMalloc(spill, waves * MPT_OT_SPILL * 64u * sizeof(uint2)));
+    *have = waves;
+    return MPT_OK;
 }
 
 // Fragment.metal:29 + Random.h:32-35: per-pixel u32 seed of the literal RNG.  The float sin-hash is
@@ -745,7 +931,7 @@ static int check_ready(mpt_ctx* ctx, const mpt_render_params* p) {
     if ((uint32_t)ctx->u.screenSize[0] != ctx->W || (uint32_t)ctx->u.screenSize[1] != ctx->H)
         return fail(ctx, MPT_ERR_INVALID_ARG, "uniforms.screenSize does not match mpt_resize");
     if (p->rng_mode < 0 || p->rng_mode > 1 || p->bsdf_mode < 0 || p->bsdf_mode > 1 || p->max_depth < 1 ||
-        p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 2 || p->shard_count < 1 || p->shard_rank < 0 ||
+        p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 3 || p->shard_count < 1 || p->shard_rank < 0 ||
         p->shard_rank >= p->shard_count || (uint64_t)p->sample_begin + p->sample_count > (1ull << 27))
         return fail(ctx, MPT_ERR_INVALID_ARG, "bad render params");
     return MPT_OK;
@@ -779,6 +965,9 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     if (rc) return rc;
     if (p->rng_mode == MPT_RNG_LITERAL && (rc = ensure_pixel_seeds(ctx))) return rc;
 
+    // the closest-first pipeline needs nested boxes and few spheres (mpt_upload_scene); otherwise the reference-order
+    // wave-local pipeline renders the same image
+    const int pipeline = p->pipeline == MPT_PIPE_ORDERED && !ctx->acc_ok ? MPT_PIPE_WAVELOCAL : p->pipeline;
     pp.scene = scene_dev(ctx);
     pp.q[0] = L.q[0];
     pp.q[1] = L.q[1];
@@ -817,16 +1006,18 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     // test mode: poison the per-path result slots so that a path that is lost shows up as NaN in the image
     if (count_flag(p)) HIPCHK(hipMemsetAsync(L.d_slots, 0xFF, pass_paths * 16, L.stream));
 
-    const size_t lds = (size_t)ctx->n_lds_nodes * 32 + (size_t)ctx->n_lds_prims * 48 + MPT_LDS_EXTRA;
+    size_t lds = (size_t)ctx->n_lds_nodes * 32 + (size_t)ctx->n_lds_prims * 48 + MPT_LDS_EXTRA;
     int per_cu = 0;
     const bool all_lds = ctx->n_lds_nodes == ctx->n_nodes;
-    const void* kfun = p->pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
-                       : p->pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
-                                                          : step_kernel(count_flag(p), all_lds);
-    // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel when the whole BVH is in
-    // LDS, 1024 otherwise)
-    const int wg_max = p->pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : 1024;
-    const int wg = ctx->wg_size > 0 && ctx->wg_size <= wg_max ? ctx->wg_size : wg_max;
+    const void* kfun = pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
+                       : pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
+                       : pipeline == MPT_PIPE_ORDERED  ? ordered_kernel(count_flag(p))
+                                                        : step_kernel(count_flag(p), all_lds);
+    // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel, mpt_ordered.h: 1024)
+    const int wg_max = pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : 1024;
+    const int wg = pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : ctx->wg_size > 0 && ctx->wg_size <= wg_max ? ctx->wg_size : wg_max;
+    AccelDev accel = {};
+    if (pipeline == MPT_PIPE_ORDERED) lds = ordered_views(ctx, (uint32_t)wg, ctx->ot_stack_depth, pp.scene, accel);
     if (ctx->occ_fun == kfun && ctx->occ_lds == lds) {
         per_cu = ctx->occ_per_cu;
     } else {
@@ -841,8 +1032,8 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     hipStream_t st = L.stream;
     *L.h_done = 0;
     hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, L.d_desc, L.d_ctr, (uint32_t)pass_paths, slots_items,
-                       (volatile uint32_t*)dev_done, p->pipeline == MPT_PIPE_WAVEFRONT ? 0 : 1);
-    if (p->pipeline == MPT_PIPE_MEGAKERNEL || p->pipeline == MPT_PIPE_WAVELOCAL) {
+                       (volatile uint32_t*)dev_done, pipeline == MPT_PIPE_WAVEFRONT ? 0 : 1);
+    if (pipeline != MPT_PIPE_WAVEFRONT) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (time_kernels) {  // events from the context's pool; they are read after the ONE sync of mpt_render / mpt_draw
             while (L.ev_pool.size() < L.ev_used + 2) {
@@ -854,7 +1045,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
             e1 = L.ev_pool[L.ev_used++];
             HIPCHK(hipEventRecord(e0, st));
         }
-        if (p->pipeline == MPT_PIPE_WAVELOCAL) {
+        if (pipeline == MPT_PIPE_WAVELOCAL || pipeline == MPT_PIPE_ORDERED) {
             const size_t waves = (size_t)grid * (wg / 64);
             if (waves > L.ring_waves) {
                 WaveRings& r = L.ring;
@@ -870,8 +1061,17 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
                 L.ring_waves = waves;
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
-            void* args[] = {(void*)&pp, (void*)&L.ring, (void*)&ctx->budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
-            HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
+            if (pipeline == MPT_PIPE_ORDERED) {
+                int src = ensure_spill(ctx, &L.d_ot_spill, &L.ot_spill_waves, waves);
+                if (src) return src;
+                accel.spill = L.d_ot_spill;
+                uint32_t walk_now = ctx->ot_walk_now_min;
+                void* args[] = {(void*)&pp, (void*)&accel, (void*)&L.ring, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div, (void*)&walk_now};
+                HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
+            } else {
+                void* args[] = {(void*)&pp, (void*)&L.ring, (void*)&ctx->budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
+                HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
+            }
         } else {
             void* args[] = {(void*)&pp};
             HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
@@ -954,7 +1154,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
 // (enqueue_stats_copy); collect_lane waits for the lane ONCE and reads the copy and the kernel-event pairs.
 static int enqueue_stats_copy(mpt_ctx* ctx, Lane& L) {
     HIPCHK(hipMemcpyAsync(L.h_desc, L.d_desc, sizeof(PassDesc), hipMemcpyDeviceToHost, L.stream));
-    HIPCHK(hipMemsetAsync(&L.d_desc->paths, 0, 8 * sizeof(unsigned long long), L.stream));
+    HIPCHK(hipMemsetAsync(&L.d_desc->paths, 0, MPT_DESC_COUNTERS * sizeof(unsigned long long), L.stream));
     HIPCHK(hipMemsetAsync(&L.d_desc->overflow, 0, 4, L.stream));
     return MPT_OK;
 }
@@ -986,6 +1186,8 @@ static int collect_lane(mpt_ctx* ctx, Lane& L) {
     ctx->stats.wave_node_iters += hd.node_iters;
     ctx->stats.wave_prim_iters += hd.prim_iters;
     ctx->stats.wave_leaf_phases += hd.leaf_phases;
+    ctx->stats.exact_retraces += hd.flagged;
+    ctx->stats.tree_parked += hd.parked;
     return MPT_OK;
 }
 
@@ -1091,32 +1293,76 @@ static int draw_impl(mpt_ctx* ctx, const mpt_render_params* p) {
 }
 
 // ---- unit-test entry points -----------------------------------------------------------------------------------
+namespace {
+struct DevBuf {  // temporary device buffer, freed on every exit path
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p) { o.p = nullptr; }
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+}  // namespace
 static int trace_rays_impl(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out,
                               int32_t* prim_out, float* normal_out, int32_t* front_out) {
     if (!ctx || !o || !d || !t_out || !prim_out || !normal_out || !front_out || n == 0 || n > (1ull << 30))
         return fail(ctx, MPT_ERR_INVALID_ARG, "bad argument");
     if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
     HIPCHK(hipSetDevice(ctx->device));
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr;
-    int *d_p = nullptr, *d_f = nullptr;
-    HIPCHK(hipMalloc(&d_o, n * 12));
-    HIPCHK(hipMalloc(&d_d, n * 12));
-    HIPCHK(hipMalloc(&d_t, n * 4));
-    HIPCHK(hipMalloc(&d_n, n * 12));
-    HIPCHK(hipMalloc(&d_p, n * 4));
-    HIPCHK(hipMalloc(&d_f, n * 4));
-    HIPCHK(hipMemcpy(d_o, o, n * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_d, d, n * 12, hipMemcpyHostToDevice));
+    DevBuf d_o, d_d, d_t, d_n, d_p, d_f;
+    HIPCHK(d_o.alloc(n * 12));
+    HIPCHK(d_d.alloc(n * 12));
+    HIPCHK(d_t.alloc(n * 4));
+    HIPCHK(d_n.alloc(n * 12));
+    HIPCHK(d_p.alloc(n * 4));
+    HIPCHK(d_f.alloc(n * 4));
+    HIPCHK(hipMemcpy(d_o.p, o, n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_d.p, d, n * 12, hipMemcpyHostToDevice));
     SceneDev sc = scene_dev(ctx);
     hipLaunchKernelGGL(k_trace_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), (size_t)ctx->n_lds_nodes * 32 + (size_t)ctx->n_lds_prims * 48 + MPT_LDS_EXTRA,
-                       ctx->stream, sc, (const float*)d_o, (const float*)d_d, (uint32_t)n, d_t, d_p, d_n, d_f);
+                       ctx->stream, sc, (const float*)d_o.p, (const float*)d_d.p, (uint32_t)n, (float*)d_t.p, (int*)d_p.p, (float*)d_n.p, (int*)d_f.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(t_out, d_t, n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(prim_out, d_p, n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(normal_out, d_n, n * 12, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(front_out, d_f, n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_n); hipFree(d_p); hipFree(d_f);
+    HIPCHK(hipMemcpy(t_out, d_t.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(prim_out, d_p.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(normal_out, d_n.p, n * 12, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(front_out, d_f.p, n * 4, hipMemcpyDeviceToHost));
+    return MPT_OK;
+}
+
+static int trace_rays_ordered_impl(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out, int32_t* prim_out,
+                                   float* normal_out, int32_t* front_out, uint32_t* flags_out) {
+    if (!ctx || !o || !d || !t_out || !prim_out || !normal_out || !front_out || !flags_out || n == 0 || n > (1ull << 22))
+        return fail(ctx, MPT_ERR_INVALID_ARG, "bad argument (at most 2^22 rays per call)");
+    if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
+    if (!ctx->acc_ok) return fail(ctx, MPT_ERR_BAD_SCENE, "closest-first walk unavailable for this scene: " + ctx->acc_why);
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf d_o, d_d, d_t, d_n, d_p, d_f, d_g, d_spill;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    HIPCHK(d_o.alloc(n * 12));
+    HIPCHK(d_d.alloc(n * 12));
+    HIPCHK(d_t.alloc(n * 4));
+    HIPCHK(d_n.alloc(n * 12));
+    HIPCHK(d_p.alloc(n * 4));
+    HIPCHK(d_f.alloc(n * 4));
+    HIPCHK(d_g.alloc(n * 4));
+    HIPCHK(d_spill.alloc((size_t)blocks * 4 * MPT_OT_SPILL * 64u * sizeof(uint2)));
+    HIPCHK(hipMemcpy(d_o.p, o, n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_d.p, d, n * 12, hipMemcpyHostToDevice));
+    SceneDev sc;
+    AccelDev ac;
+    const size_t lds = ordered_views(ctx, 256, ctx->ot_stack_depth, sc, ac);
+    ac.spill = (uint2*)d_spill.p;
+    hipLaunchKernelGGL(k_trace_rays_ordered, dim3(blocks), dim3(256), lds, ctx->stream, sc, ac, (const float*)d_o.p, (const float*)d_d.p,
+                       (uint32_t)n, (float*)d_t.p, (int*)d_p.p, (float*)d_n.p, (int*)d_f.p, (uint32_t*)d_g.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(t_out, d_t.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(prim_out, d_p.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(normal_out, d_n.p, n * 12, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(front_out, d_f.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(flags_out, d_g.p, n * 4, hipMemcpyDeviceToHost));
     return MPT_OK;
 }
 
@@ -1124,18 +1370,21 @@ template <typename F>
 static int kat_run(mpt_ctx* ctx, const void* const* in, const size_t* in_bytes, int n_in, void* const* out,
                    const size_t* out_bytes, int n_out, F launch) {
     HIPCHK(hipSetDevice(ctx->device));
+    std::vector<DevBuf> bi(n_in), bo(n_out);
     std::vector<void*> di(n_in), dout(n_out);
     for (int i = 0; i < n_in; ++i) {
-        HIPCHK(hipMalloc(&di[i], in_bytes[i]));
+        HIPCHK(bi[i].alloc(in_bytes[i]));
+        di[i] = bi[i].p;
         HIPCHK(hipMemcpy(di[i], in[i], in_bytes[i], hipMemcpyHostToDevice));
     }
-    for (int i = 0; i < n_out; ++i) HIPCHK(hipMalloc(&dout[i], out_bytes[i]));
+    for (int i = 0; i < n_out; ++i) {
+        HIPCHK(bo[i].alloc(out_bytes[i]));
+        dout[i] = bo[i].p;
+    }
     launch(di, dout);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n_out; ++i) HIPCHK(hipMemcpy(out[i], dout[i], out_bytes[i], hipMemcpyDeviceToHost));
-    for (auto p : di) hipFree(p);
-    for (auto p : dout) hipFree(p);
     return MPT_OK;
 }
 
@@ -1236,6 +1485,18 @@ extern "C" int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p) {
 
 extern "C" int mpt_trace_rays(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out, int32_t* prim_out, float* normal_out, int32_t* front_out) {
     return guarded(ctx, [&] { return trace_rays_impl(ctx, o, d, n, t_out, prim_out, normal_out, front_out); });
+}
+
+extern "C" int mpt_trace_rays_ordered(mpt_ctx* ctx, const float* o, const float* d, uint64_t n, float* t_out, int32_t* prim_out, float* normal_out, int32_t* front_out, uint32_t* flags_out) {
+    return guarded(ctx, [&] { return trace_rays_ordered_impl(ctx, o, d, n, t_out, prim_out, normal_out, front_out, flags_out); });
+}
+
+extern "C" int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]) {
+    if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
+    const uint64_t v[8] = {ctx->acc_ok ? 1u : 0u, ctx->n_acc_nodes, ctx->acc_depth, ctx->ot_lds_nodes, ctx->n_always, ctx->n_ref_leaves, ctx->ot_lds_prims, 0};
+    memcpy(out, v, sizeof v);
+    return MPT_OK;
 }
 
 extern "C" int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* h, float* f) {

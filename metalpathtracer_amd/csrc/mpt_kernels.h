@@ -41,7 +41,9 @@ struct PassDesc {
     uint32_t slots_items;  // wavefront width in 64-slot items
     uint32_t done, overflow, iterations;
     unsigned long long paths, rays, node_visits, aabb_hits, prim_tests, node_iters, prim_iters, leaf_phases;
+    unsigned long long flagged, parked;  // closest-first pipeline: rays handed to the reference-order walk / parked for the tree
 };
+#define MPT_DESC_COUNTERS 10
 
 // Atomic counters live on lines of their own (MPT_CTR_STRIDE words apart): device-scope atomics are
 // executed at the memory side, and counters that share a line serialise there.
@@ -175,8 +177,8 @@ __device__ __forceinline__ void rng_for_path(const PassParams& pp, uint32_t path
 __device__ __forceinline__ void stage_nodes(const SceneDev& sc, float4* lds) {
     const uint32_t n4 = sc.n_lds_nodes * 2u, p4 = sc.n_lds_prims * 3u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = sc.nodes[i];
-    for (uint32_t i = threadIdx.x; i < p4; i += blockDim.x) lds[n4 + i] = sc.prims[i];
-    for (uint32_t i = threadIdx.x; i < sc.n_lds_mats * 2u; i += blockDim.x) lds[n4 + p4 + i] = sc.mats[i];
+    for (uint32_t i = threadIdx.x; i < p4; i += blockDim.x) lds[sc.lds_prim_off + i] = sc.prims[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_lds_mats * 2u; i += blockDim.x) lds[sc.lds_mat_off + i] = sc.mats[i];
     __syncthreads();
 }
 

@@ -835,6 +835,11 @@ struct Hit {  // Structs.h:12-20
 // Filled only when enabled (orc_histogram_enable); used to size the GPU pipeline's traversal budgets.
 static uint64_t g_hist[2][256];
 static bool g_hist_on = false;
+// Optional observer of every closest-hit query of a render (tests of alternative traversal orders compare their own
+// answer with the reference-order one, ray by ray).  Called from the render threads; null = off.
+typedef void (*RayHook)(const float o[3], const float d[3], float t, int primitiveId, void* user);
+static RayHook g_ray_hook = nullptr;
+static void* g_ray_hook_user = nullptr;
 
 struct Counters {
     uint64_t rays, node_pops, aabb_pass, prim_tests, sphere_tests, tri_tests, pushes, misses, bounces, emissive_hits,
@@ -1024,6 +1029,10 @@ static void ray_color(Ray r, const float* bvh, const float* prims, const float* 
         if (g_hist_on) {
             uint64_t n = ct->node_pops - pops_before;
             __atomic_fetch_add(&g_hist[depth == 0 ? 0 : 1][n > 255 ? 255 : n], 1, __ATOMIC_RELAXED);
+        }
+        if (g_ray_hook) {
+            const float ro[3] = {r.o.x, r.o.y, r.o.z}, rd[3] = {r.d.x, r.d.y, r.d.z};
+            g_ray_hook(ro, rd, hit.t, hit.primitiveId, g_ray_hook_user);
         }
         if (hit.primitiveId == -1) {  // PathTracing.h:225-232
             V3 ud = normalize(r.d);
@@ -1347,6 +1356,10 @@ void orc_histogram_enable(int on) {
     if (on) memset(g_hist, 0, sizeof g_hist);
 }
 void orc_histogram_read(uint64_t* out512) { memcpy(out512, g_hist, sizeof g_hist); }
+void orc_set_ray_hook(RayHook hook, void* user) {
+    g_ray_hook_user = user;
+    g_ray_hook = hook;
+}
 
 // FNV-1a 64 over a byte range (image hashes).
 uint64_t orc_fnv1a64(const void* data, uint64_t nbytes) {
