@@ -12,7 +12,12 @@ steps and, for N > 1, the one RCCL reduce of the HDR framebuffer (the K steps ac
 interleaved over the ranks (strong scaling: the job is fixed, `value` = all rays of the job / max-over-ranks time).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel vs the HBM roof, algorithmic bytes per ray per SURVEY.md 8(d)
+  roofline      dominant kernel vs the two roofs it can be measured against: vector-ALU instruction issue (wave64
+                instructions x 2 cycles on a SIMD-32) and measured HBM traffic; `frac` is the larger of the two and
+                cannot exceed 1.  The per-ray instruction / byte figures come from the committed rocprofv3 --pmc passes of
+                the same build and workload (profiles/), scaled by this run's rays per launch and HIP-event launch time.
+                The SURVEY.md 8(d) algorithmic bytes per ray are kept under `algorithmic` (they price LDS-served BVH
+                reads as HBM and so exceed the HBM peak: not a bound).
   cpu_baseline  the CPU oracle (this repo's restatement of the reference algorithm; the reference has no CPU
                 path) timed on the host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -26,8 +31,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 1024          # 256 CUs x 4 SIMD-32; a wave64 VALU instruction occupies its SIMD for 2 cycles (same guide)
+MAX_CLOCK_GHZ = 2.4
 B_QUEUE = 168.0        # compulsory wavefront-queue bytes per ray
-PIPE_NAMES = {0: "wavefront (global SoA queues)", 1: "megakernel", 2: "wave-local wavefront"}
+PIPE_NAMES = {0: "wavefront (global SoA queues)", 1: "megakernel", 2: "wave-local wavefront, reference-order walk",
+              3: "wave-local wavefront, closest-first walk of the own 4-wide BVH"}
+PIPE_KERNEL = {0: "k_step", 1: "k_megakernel", 2: "k_wavelocal", 3: "k_ordered"}
+PIPE_PROFILE = {2: "r02_pmc_wavelocal.json", 3: "r02_pmc_ordered.json"}
 
 
 def parse():
@@ -41,37 +51,33 @@ def parse():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "scene.xml"))
     ap.add_argument("--pipeline", default=os.environ.get("MPT_BENCH_PIPELINE", "default"),
-                    choices=["default", "wavefront", "megakernel", "wavelocal"])
+                    choices=["default", "wavefront", "megakernel", "wavelocal", "ordered"])
     ap.add_argument("--slots", type=int, default=0, help="wavefront width (ray slots per iteration), 0 = default")
     ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-def measured_traffic(pipe, rays_per_launch):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate runs, gfx950 x2 read
-    correction applied).  PMC cannot be collected from inside this process, so the per-ray figure measured on the
-    same workload and pipeline is scaled by this run's rays per launch; None when no matching profile exists."""
+def counter_profile(pipe):
+    """Per-launch counters of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_round.sh on
+    tools/prof_run.py: same scene / size / spp / depth as the default bench step; PMC cannot be collected from inside
+    this process).  Returns per-ray figures, or None when no profile of this pipeline is committed."""
     try:
-        if pipe != 2:
-            return None
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        return prof["traffic_bytes_per_ray"] * rays_per_launch
-    except Exception:
-        return None
-
-
-def issue_profile(pipe):
-    """What actually bounds the dominant kernel (from the same committed PMC passes): VALU wave-instructions per ray and
-    the fraction of their lane slots that did work."""
-    try:
-        if pipe != 2:
-            return None
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        return {"valu_wave_instr_per_ray": prof["valu_wave_instr_per_ray"],
-                "valu_lane_utilisation": prof["valu_lane_utilisation"], "l2_hit_rate": prof["l2_hit_rate"],
-                "source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, same workload)"}
+        prof = json.load(open(os.path.join(ROOT, "profiles", PIPE_PROFILE[pipe])))
+        c, rays, ms = prof["counters"], float(prof["rays_per_launch"]), float(prof["kernel_ms"])
+        clock_ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e-3) / 1e9
+        return {
+            "file": "profiles/" + PIPE_PROFILE[pipe],
+            "valu_per_ray": c["SQ_INSTS_VALU"] / rays, "salu_per_ray": c["SQ_INSTS_SALU"] / rays,
+            "lds_per_ray": c["SQ_INSTS_LDS"] / rays,
+            "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
+            "hbm_bytes_per_ray": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / rays,   # gfx950: FETCH_SIZE x2
+            "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+            "clock_ghz": clock_ghz,
+            "wave_cycles_split": {k: c[n] / c["SQ_WAVE_CYCLES"] for k, n in
+                                  (("issuing", "SQ_ACTIVE_INST_ANY"), ("waitcnt", "SQ_WAIT_ANY"), ("issue_stall", "SQ_WAIT_INST_ANY"))},
+            "profiled_kernel_ms": ms,
+        }
     except Exception:
         return None
 
@@ -162,7 +168,7 @@ def main():
     fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     ctx.set_sum_buffer(fb.data_ptr())
     pipe = {"default": capi.DEFAULT_PIPELINE, "wavefront": capi.PIPE_WAVEFRONT, "megakernel": capi.PIPE_MEGAKERNEL,
-            "wavelocal": capi.PIPE_WAVELOCAL}[args.pipeline]
+            "wavelocal": capi.PIPE_WAVELOCAL, "ordered": capi.PIPE_ORDERED}[args.pipeline]
     kw = dict(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_LAMBERT, max_depth=args.depth, pipeline=pipe, seed=(1, 0),
               shard_rank=rank, shard_count=world, slots_per_iter=args.slots)
 
@@ -202,6 +208,14 @@ def main():
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
     rays_local = st["rays"]
+    image_mean = (fb[..., :3].double().mean(dim=(0, 1)) / (args.steps * spp)).tolist() if rank == 0 else None
+    # untimed extra (N = 1): ONE render at a time, no overlap of consecutive steps — what a single 256-spp frame takes
+    serial_ms = []
+    if world == 1:
+        for k in range(min(3, args.steps)):
+            ctx.render(sample_begin=(args.steps + k) * spp, sample_count=spp, **kw)
+            serial_ms.append(ctx.stats()["total_ms"])
+    serial_ms = sum(serial_ms) / len(serial_ms) if serial_ms else None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -213,7 +227,7 @@ def main():
         rays_total, paths_total = rays_local, st["paths"]
 
     if rank == 0:
-        mean = (fb[..., :3].double().mean(dim=(0, 1)) / (args.steps * spp)).tolist()
+        mean = image_mean
         out = {
             "metric": "Mrays/s at 1920x1080x256spp on scene.xml",
             "value": rays_total / elapsed / 1e6,
@@ -242,26 +256,47 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
             out["cpu_baseline"], (n_node, n_prim, h) = cpu_baseline(args, buffers, P, T)
         b_ray = B_QUEUE + 32.0 * n_node + 52.0 * n_prim + 32.0 * h
+        out["serial_ms_per_render"] = serial_ms
+        out["config"]["serial_mrays_per_s"] = rays_local / args.steps / serial_ms / 1e3 if serial_ms else None
         if launches and kernel_ms > 0:
             rays_per_launch = rays_local / launches
             sec_per_launch = kernel_ms * 1e-3 / launches
-            achieved = b_ray * rays_per_launch / sec_per_launch / 1e9
-            out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(pipe, rays_per_launch),
-                "kernel": {0: "k_step", 1: "k_megakernel", 2: "k_wavelocal"}[pipe],
-                "launches": launches, "avg_launch_ms": kernel_ms / launches,
+            prof = counter_profile(pipe)
+            rf = {"kernel": PIPE_KERNEL[pipe], "launches": launches, "avg_launch_ms": kernel_ms / launches,
+                  "rays_per_launch": rays_per_launch}
+            if prof:
+                # vector-ALU issue: wave64 instructions per second vs 1024 SIMD-32s issuing one every 2 cycles
+                valu_rate = prof["valu_per_ray"] * rays_per_launch / sec_per_launch / 1e9            # G wave-instr/s
+                valu_peak = N_SIMD * prof["clock_ghz"] / 2.0
+                hbm_bytes = prof["hbm_bytes_per_ray"] * rays_per_launch
+                hbm_rate = hbm_bytes / sec_per_launch / 1e9
+                valu_frac, hbm_frac = valu_rate / valu_peak, hbm_rate / HBM_PEAK_GBS
+                if valu_frac >= hbm_frac:
+                    rf.update(bound="valu", achieved=valu_rate, peak=valu_peak, unit="G wave64-instr/s", frac=valu_frac)
+                else:
+                    rf.update(bound="hbm", achieved=hbm_rate, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac)
+                rf["traffic"] = hbm_bytes
+                rf["valu"] = {"achieved": valu_rate, "peak": valu_peak, "unit": "G wave64-instr/s", "frac": valu_frac,
+                              "frac_at_2.4GHz": valu_rate / (N_SIMD * MAX_CLOCK_GHZ / 2.0), "instr_per_ray": prof["valu_per_ray"],
+                              "lane_utilisation": prof["lane_utilisation"], "useful_lane_frac": valu_frac * prof["lane_utilisation"],
+                              "salu_per_valu": prof["salu_per_ray"] / prof["valu_per_ray"], "clock_ghz": prof["clock_ghz"]}
+                rf["hbm"] = {"achieved": hbm_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                             "bytes_per_ray": prof["hbm_bytes_per_ray"], "l2_hit_rate": prof["l2_hit_rate"]}
+                rf["wave_cycles_split"] = prof["wave_cycles_split"]
+                rf["source"] = ("%s (rocprofv3 --pmc, one counter set per pass, same build / scene / size / spp: per-ray "
+                                "counters x this run's rays per launch / this run's HIP-event launch time; the profiled "
+                                "launch took %.2f ms)" % (prof["file"], prof["profiled_kernel_ms"]))
+            else:
+                rf.update(bound="valu", achieved=None, peak=None, unit="G wave64-instr/s", frac=None, traffic=None,
+                          source="no committed counter profile for this pipeline")
+            rf["algorithmic"] = {
                 "bytes_per_ray": b_ray, "n_node": n_node, "n_prim": n_prim, "h": h,
-                "rays_per_launch": rays_per_launch,
-                "algorithmic_bytes_per_launch": b_ray * rays_per_launch,
-                "note": "achieved = SURVEY 8(d) algorithmic bytes/ray x rays per launch / avg launch time; frac > 1 "
-                        "means the kernel is not HBM-bound: the scene (0.5 MB) is served from LDS/L2; `traffic` = measured "
-                        "L2<->fabric bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json); the kernel is "
-                        "VALU-issue-bound, see `issue`",
-            }
-            issue = issue_profile(pipe)
-            if issue:
-                out["roofline"]["issue"] = issue
+                "bytes_per_launch": b_ray * rays_per_launch,
+                "gbs_if_all_of_it_were_hbm": b_ray * rays_per_launch / sec_per_launch / 1e9,
+                "note": "SURVEY 8(d): 168 + 32 n_node + 52 n_prim + 32 h with the reference walk's counts from the CPU oracle "
+                        "in this run; BVH reads are served from LDS and primary rays never leave registers, so this figure is "
+                        "not HBM traffic and is not used as a bound"}
+            out["roofline"] = rf
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -181,6 +181,35 @@ int mpt_trace_rays_ordered(mpt_ctx* ctx, const float* origins, const float* dire
  * [6] primitives staged in LDS, [7] reserved.                                                                          */
 int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 
+/* BVH construction on the GPU — stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,
+ * 195-317: sequential full-sweep SAH, 8.2 s for 1 M primitives): a linear BVH (63-bit Morton codes, radix sort, Karras'
+ * radix tree, bottom-up refit) with leaves of <= 8 primitives, written in the REFERENCE's buffer format so that
+ * mpt_upload_scene (and the reference's shader, and the oracle) can consume it: bvh_out = 2 float4 per node as
+ * Scene::createBVHBuffer returns them (root = node 0), prim_idx_out = Scene::createPrimitiveIndexBuffer.
+ * prims: the 3-float4-per-primitive array of Scene::createTransformsBuffer (host memory, already sorted spheres first as
+ * Scene::buildBVH does, Scene.h:72-75).  bvh_capacity_nodes >= 2 * n_prims - 1 is always enough.  device_ms_out
+ * (optional): HIP-event time of the build kernels.  Parent boxes are exact unions of child boxes.                      */
+int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims, float* bvh_out, uint64_t bvh_capacity_nodes,
+                  uint64_t* n_nodes_out, int32_t* prim_idx_out, double* device_ms_out);
+
+/* ---- multi-GPU: tile shards + ONE RCCL reduce of the HDR sum over xGMI ---------------------------------
+ * The reference is single-GPU (it presents straight to the drawable, R/Renderer/Renderer.cpp:303-307); this is the
+ * product's extension.  Every GPU renders the 8x8 pixel tiles t % N == rank (mpt_render_params.shard_rank / shard_count)
+ * at full spp into its own zero-initialised HDR sum; mpt_reduce_sum adds the N buffers onto the root's with
+ * ncclReduce(sum, float32, 4*W*H) — each pixel has exactly one owner, so the result is bit-identical to one GPU's.
+ * librccl.so is opened on first use (dlopen): nothing here needs it for N = 1, where the reduce is a no-op.
+ *   one host thread, N contexts:   mpt_comm_create_all(ctxs, N, &comm)            (ncclCommInitAll)
+ *   one process per GPU:           rank 0: mpt_comm_unique_id(id); every rank: mpt_comm_create_rank(ctx, r, N, id, &comm)
+ * All contexts of a communicator must have the same size (mpt_resize).                                                  */
+typedef struct mpt_comm mpt_comm;
+#define MPT_COMM_ID_BYTES 128
+int mpt_comm_unique_id(void* id_out /* MPT_COMM_ID_BYTES */);
+int mpt_comm_create_all(mpt_ctx* const* ctxs, int n, mpt_comm** out);
+int mpt_comm_create_rank(mpt_ctx* ctx, int rank, int nranks, const void* id /* MPT_COMM_ID_BYTES */, mpt_comm** out);
+int mpt_reduce_sum(mpt_comm* comm, int root);   /* waits for the renders in flight, reduces, returns when the root holds the image */
+int mpt_comm_destroy(mpt_comm* comm);
+const char* mpt_comm_last_error(const mpt_comm* comm);
+
 /* RNG known-answer hooks evaluated ON THE DEVICE (Random.h:6-16 and the philox / sincos spec).      */
 int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* hash_out, float* float_out);
 int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* ctr4, const uint32_t* key2, uint64_t n, uint32_t* out4);

@@ -23,7 +23,8 @@ extern "C" {
 typedef struct mpt_scene mpt_scene;
 typedef struct mpt_renderer mpt_renderer;
 
-enum { MPT_BVH_REFERENCE_SWEEP = 0, MPT_BVH_BINNED_CENTROID = 1 };
+enum { MPT_BVH_REFERENCE_SWEEP = 0, MPT_BVH_BINNED_CENTROID = 1,
+       MPT_BVH_GPU_LBVH = 2 /* built on the GPU by mpt_build_bvh (include/mpt.h); needs a device */ };
 enum { MPT_PRIM_SPHERE = 0, MPT_PRIM_TRIANGLE = 1 };
 
 /* Scene (R/Scene/Scene.h) */

@@ -27,6 +27,8 @@ SYMBOLS = (
     "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
     "mpt_read_frame", "mpt_read_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
     "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
+    "mpt_build_bvh", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
+    "mpt_comm_last_error",
 )
 
 
@@ -118,6 +120,14 @@ def load():
     L.mpt_trace_rays.argtypes = [vp, fp, fp, C.c_uint64, fp, ip, fp, ip]
     L.mpt_trace_rays_ordered.argtypes = [vp, fp, fp, C.c_uint64, fp, ip, fp, ip, up]
     L.mpt_accel_info.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.mpt_build_bvh.argtypes = [vp, fp, C.c_uint64, fp, C.c_uint64, C.POINTER(C.c_uint64), ip, C.POINTER(C.c_double)]
+    L.mpt_comm_unique_id.argtypes = [vp]
+    L.mpt_comm_create_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+    L.mpt_comm_create_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.mpt_reduce_sum.argtypes = [vp, C.c_int]
+    L.mpt_comm_destroy.argtypes = [vp]
+    L.mpt_comm_last_error.argtypes = [vp]
+    L.mpt_comm_last_error.restype = C.c_char_p
     L.mpt_kat_pcg.argtypes = [vp, up, C.c_uint64, up, fp]
     L.mpt_kat_philox.argtypes = [vp, up, up, C.c_uint64, up]
     L.mpt_kat_sincos.argtypes = [vp, fp, C.c_uint64, fp, fp]
@@ -135,6 +145,54 @@ def _ip(a):
 
 def _up(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Comm:
+    """RCCL communicator over the C ABI (mpt_comm_*): `Comm.all([ctx0, ctx1, ...])` for N contexts driven by this
+    process, or `Comm.rank(ctx, rank, nranks, id_bytes)` with `Comm.unique_id()` from rank 0 for one process per GPU."""
+
+    def __init__(self, handle, ctxs):
+        self.L = load()
+        self.h = handle
+        self.ctxs = ctxs
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load().mpt_comm_unique_id(buf)
+        if rc:
+            raise MptError(rc, "mpt_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def all(cls, ctxs):
+        L = load()
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        h = C.c_void_p()
+        rc = L.mpt_comm_create_all(arr, len(ctxs), C.byref(h))
+        if rc:
+            raise MptError(rc, "mpt_comm_create_all", (L.mpt_last_error(ctxs[0].h) or b"").decode())
+        return cls(h, list(ctxs))
+
+    @classmethod
+    def rank(cls, ctx, rank, nranks, id_bytes=None):
+        L = load()
+        h = C.c_void_p()
+        buf = C.create_string_buffer(id_bytes, 128) if id_bytes else None
+        rc = L.mpt_comm_create_rank(ctx.h, int(rank), int(nranks), buf, C.byref(h))
+        if rc:
+            raise MptError(rc, "mpt_comm_create_rank", (L.mpt_last_error(ctx.h) or b"").decode())
+        return cls(h, [ctx])
+
+    def reduce_sum(self, root=0):
+        rc = self.L.mpt_reduce_sum(self.h, int(root))
+        if rc:
+            raise MptError(rc, "mpt_reduce_sum", (self.L.mpt_comm_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.L.mpt_comm_destroy(self.h)
+            self.h = None
 
 
 class Context:
@@ -264,6 +322,17 @@ class Context:
         self._chk(self.L.mpt_trace_rays_ordered(self.h, _fp(o), _fp(d), n, _fp(t), _ip(prim), _fp(nrm), _ip(front),
                                                 _up(flags)), "mpt_trace_rays_ordered")
         return t, prim, nrm, front, flags
+
+    def build_bvh(self, prims):
+        """GPU LBVH over the packed primitive array (12 floats each) -> (bvh [N, 8] f32, prim_idx [P] i32, device ms)."""
+        prims = np.ascontiguousarray(prims, np.float32).reshape(-1, 12)
+        n = prims.shape[0]
+        bvh = np.zeros((2 * n - 1, 8), np.float32)
+        idx = np.zeros(n, np.int32)
+        nn, ms = C.c_uint64(), C.c_double()
+        self._chk(self.L.mpt_build_bvh(self.h, _fp(prims), n, _fp(bvh), 2 * n - 1, C.byref(nn), _ip(idx), C.byref(ms)),
+                  "mpt_build_bvh")
+        return bvh[: nn.value].copy(), idx, ms.value
 
     def accel_info(self):
         out = (C.c_uint64 * 8)()

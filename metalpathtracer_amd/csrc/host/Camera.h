@@ -43,11 +43,17 @@ inline void reset() {  // R/Renderer/Camera.h:24-32
     focalLength = 1.0f;
 }
 
-// rotate v about the (unnormalised) axis by angle: the action of the quaternion simd::quatf(angle, axis)
+// simd_act(simd::quatf(angle, axis), v) as Apple's <simd/quaternion.h> defines the two (that SDK header is not part of
+// the reference tree): q = (sin(angle/2) * axis, cos(angle/2)) WITHOUT normalising the axis, and
+// act(q, v) = v + q.real * t + cross(q.imag, t) with t = 2 cross(q.imag, v).  The reference passes
+// cross(forward, worldUp) as the axis (R/Renderer/Camera.h:53-54), which is shorter than 1 once the camera pitches: the
+// result is then not a pure rotation, and is reproduced as such (the callers normalise it, as the reference does).
 inline mpt::float3 rotateAbout(const mpt::float3& v, float angle, const mpt::float3& axis) {
-    const mpt::float3 k = mpt::normalize(axis);
-    const float c = std::cos(angle), s = std::sin(angle);
-    return v * c + mpt::cross(k, v) * s + k * (mpt::dot(k, v) * (1.0f - c));
+    const float half = angle * 0.5f;
+    const mpt::float3 imag = axis * std::sin(half);
+    const float real = std::cos(half);
+    const mpt::float3 t = mpt::cross(imag, v) * 2.0f;
+    return v + t * real + mpt::cross(imag, t);
 }
 
 inline bool move(const mpt::float3& dir) {  // R/Renderer/Camera.h:35-47

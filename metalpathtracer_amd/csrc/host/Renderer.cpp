@@ -49,11 +49,19 @@ Renderer::Renderer(int deviceOrdinal, const std::string& scenePath, const std::s
     Camera::reset();
     Camera::screenSize = mpt::float2{1280.0f, 720.0f};  // R/Renderer/Renderer.cpp:48-49
     if (!scenePath_.empty()) {
-        updateVisibleScene();
-        buildShaders();
-        buildBuffers();
-        buildTextures();
-        recalculateViewport();
+        try {
+            updateVisibleScene();
+            buildShaders();
+            buildBuffers();
+            buildTextures();
+            recalculateViewport();
+        } catch (...) {  // the destructor does not run for a constructor that throws
+            mpt_destroy(ctx_);
+            ctx_ = nullptr;
+            delete scene_;
+            scene_ = nullptr;
+            throw;
+        }
     }
 }
 

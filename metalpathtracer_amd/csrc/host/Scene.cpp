@@ -8,6 +8,11 @@
 // so even its (library-specific) tie order is reproduced under libstdc++.
 #include "Scene.h"
 
+#include "mpt.h"
+#include <string>
+#include <stdexcept>
+#include <memory>
+
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -290,6 +295,10 @@ void Scene::buildBVH(BuildMode mode) {
         nodes_.push_back(n);
         return;
     }
+    if (mode == BuildMode::GpuLbvh) {
+        buildOnGpu();
+        return;
+    }
     BuildContext ctx(primitives_, primitiveIndices_, nodes_);
     // levels of forking: 2^forks concurrent subtree tasks at most (MPT_BUILD_THREADS=1 builds sequentially)
     unsigned threads = std::thread::hardware_concurrency();
@@ -300,6 +309,38 @@ void Scene::buildBVH(BuildMode mode) {
         ctx.buildSweep(nodes_, 0, primitives_.size(), forks);
     else
         ctx.buildBinned(nodes_, 0, primitives_.size(), forks);
+}
+
+// The GPU builder (include/mpt.h: mpt_build_bvh) takes the packed primitive array and returns the reference's two
+// buffers; they are unpacked into nodes_ / primitiveIndices_ so that every accessor and packer works as after a host build.
+void Scene::buildOnGpu() {
+    int device = 0;
+    if (const char* e = std::getenv("MPT_BUILD_DEVICE")) device = std::atoi(e);
+    mpt_ctx* ctx = nullptr;
+    int rc = mpt_create(device, &ctx);
+    if (rc != MPT_OK)
+        throw std::runtime_error(std::string("Scene::buildBVH(GpuLbvh): mpt_create: ") + mpt_status_string(rc) +
+                                 " — a MI355X GPU is required, there is no CPU fallback");
+    const size_t n = primitives_.size();
+    std::unique_ptr<float4[]> packed(createTransformsBuffer());
+    std::vector<float> bvh((2 * n - 1) * 8);
+    std::vector<int32_t> idx(n);
+    uint64_t nn = 0;
+    double ms = 0.0;
+    rc = mpt_build_bvh(ctx, reinterpret_cast<const float*>(packed.get()), n, bvh.data(), 2 * n - 1, &nn, idx.data(), &ms);
+    std::string err = rc ? mpt_last_error(ctx) : "";
+    mpt_destroy(ctx);
+    if (rc != MPT_OK) throw std::runtime_error("Scene::buildBVH(GpuLbvh): " + err);
+    lastGpuBuildMs_ = ms;
+    nodes_.resize(nn);
+    for (size_t i = 0; i < nn; ++i) {
+        const float* q = bvh.data() + 8 * i;
+        nodes_[i].boundsMin = float3(q[0], q[1], q[2]);
+        nodes_[i].boundsMax = float3(q[4], q[5], q[6]);
+        std::memcpy(&nodes_[i].leftFirst, q + 3, 4);
+        std::memcpy(&nodes_[i].count, q + 7, 4);
+    }
+    for (size_t i = 0; i < n; ++i) primitiveIndices_[i] = static_cast<size_t>(idx[i]);
 }
 
 int Scene::getBVHDepth() const {

@@ -36,7 +36,9 @@ class Scene {
 public:
     enum class BuildMode {
         ReferenceSweep,  // full-sweep SAH keyed on data0[axis], leaf <= 8 (R/Scene/Scene.h:195-317): same tree
-        BinnedCentroid   // 16-bin SAH on centroids, O(n log n): for large scenes; image-equivalent, not tree-equal
+        BinnedCentroid,  // 16-bin SAH on centroids, O(n log n): for large scenes; image-equivalent, not tree-equal
+        GpuLbvh          // linear BVH built on the GPU (mpt_build_bvh: Morton sort + Karras tree, leaves <= 8); needs a
+                         // device (MPT_BUILD_DEVICE, default 0) and throws without one — there is no CPU fallback
     };
 
     Scene() = default;
@@ -54,6 +56,7 @@ public:
     size_t getBVHNodeCount() const { return nodes_.size(); }
     const std::vector<BVHNode>& getBVHNodes() const { return nodes_; }
     int getBVHDepth() const;
+    double lastGpuBuildMs() const { return lastGpuBuildMs_; }   // HIP-event time of the last GpuLbvh build
 
     // Flat buffers in the layout the hot path consumes.  Caller owns the arrays (delete[]).
     mpt::float4* createTransformsBuffer() const;       // 3 float4 / primitive
@@ -65,9 +68,11 @@ public:
     void createTriangleBuffers(std::vector<mpt::float3>& outVertices, std::vector<mpt::uint3>& outIndices) const;
 
 private:
+    void buildOnGpu();
     std::vector<Primitive> primitives_;
     std::vector<size_t> primitiveIndices_;
     std::vector<BVHNode> nodes_;
+    double lastGpuBuildMs_ = 0.0;
 };
 
 }  // namespace MetalCppPathTracer

@@ -32,6 +32,12 @@ namespace {
 using mpt::float3;
 
 // ------------------------------------------------------------------------------------------ numbers
+// objDouble restates tryParseDouble of tinyobjloader 2.0.0 (the OBJ reader the reference vendors and calls,
+// R/tiny_obj_loader.h:897-1028) so that every vertex gets the same bits as in the reference.  tinyobjloader is
+// Copyright (c) 2012-Present Syoyo Fujita and many contributors, MIT License: "Permission is hereby granted, free of
+// charge, to any person obtaining a copy of this software and associated documentation files (the "Software"), to deal
+// in the Software without restriction ... The above copyright notice and this permission notice shall be included in
+// all copies or substantial portions of the Software."  Full text: THIRD_PARTY_NOTICES.md.
 bool objDouble(const char* s, const char* end, double* out) {
     if (s >= end) return false;
     const char* c = s;

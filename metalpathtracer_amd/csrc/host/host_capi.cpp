@@ -2,6 +2,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdio>
+#include <memory>
 #include <cstring>
 #include <exception>
 #include <limits>
@@ -99,9 +100,9 @@ int mpt_scene_add_primitive(mpt_scene* s, int type, const float d0[3], const flo
     })
 }
 int mpt_scene_build_bvh(mpt_scene* s, int mode) {
-    if (!s || (mode != 0 && mode != 1)) return MPT_ERR_INVALID_ARG;
+    if (!s || mode < 0 || mode > 2) return MPT_ERR_INVALID_ARG;
     SCENE_GUARD(MPT_ERR_HIP, {
-        s->sc->buildBVH(mode == 0 ? Scene::BuildMode::ReferenceSweep : Scene::BuildMode::BinnedCentroid);
+        s->sc->buildBVH(mode == 0 ? Scene::BuildMode::ReferenceSweep : mode == 1 ? Scene::BuildMode::BinnedCentroid : Scene::BuildMode::GpuLbvh);
         return MPT_OK;
     })
 }
@@ -199,9 +200,10 @@ int mpt_renderer_create(int device, const char* xml_path, const char* asset_root
     if (!out) return MPT_ERR_INVALID_ARG;
     *out = nullptr;
     try {
-        mpt_renderer* h = new mpt_renderer();
-        h->r = new Renderer(device, xml_path ? xml_path : "", asset_root ? asset_root : "");
-        *out = h;
+        std::unique_ptr<Renderer> r(new Renderer(device, xml_path ? xml_path : "", asset_root ? asset_root : ""));
+        std::unique_ptr<mpt_renderer> h(new mpt_renderer());
+        h->r = r.release();
+        *out = h.release();
         return MPT_OK;
     } catch (const std::exception& e) {
         copy_text(e.what(), err, err_cap);

@@ -1,9 +1,11 @@
 // main.cpp — mpt_render: headless command-line front end of the host Renderer.
 // (The reference's main.cpp starts an NSApplication + MTKView, R/main.cpp:15-28; that shell is out of scope.)
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -18,14 +20,170 @@ static void usage() {
     std::puts(
         "mpt_render --scene scene.xml [--asset-root DIR] [--width 1280] [--height 720]\n"
         "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter]\n"
-        "           [--pipeline wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
+        "           [--pipeline ordered|wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
         "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
-        "  --frames N   run the reference's frame protocol (N draw() calls, running mean) instead of batch spp");
+        "           [--gpus N] [--camera-path FILE [--out-dir runs]]\n"
+        "  --frames N        run the reference's frame protocol (N draw() calls, running mean) instead of batch spp\n"
+        "  --gpus N          batch mode on GPUs device .. device+N-1: 8x8 pixel tiles interleaved over the GPUs, one RCCL\n"
+        "                    reduce(sum) of the HDR framebuffer onto the first (mpt_comm_create_all / mpt_reduce_sum)\n"
+        "  --camera-path F   headless replay of the reference's input handling (R/Window/ControllerView.mm:41-73): one\n"
+        "                    line of F per frame, optionally prefixed by a repeat count, holding the keys\n"
+        "                    w a s d space c (move), r (reset), `mouse dx dy`, `scroll dy`; every frame is one draw()\n"
+        "                    and is written to <out-dir>/frame_NNNN.ppm (default out-dir: runs, as R/runs/)");
+}
+
+// One frame of input in the reference's vocabulary (R/Window/ControllerView.mm:41-73): held keys set the movement
+// vector to +-1 per axis (keyDown), `r` requests a reset, a mouse drag gives the rotation deltas, the scroll wheel the
+// zoom (negated, :70-72).  Camera::transformWithInputs() consumes and clears them inside the next draw().
+static bool applyInputLine(const std::string& line, int* repeat) {
+    std::vector<std::string> tok;
+    size_t i = 0;
+    while (i < line.size()) {
+        while (i < line.size() && std::isspace((unsigned char)line[i])) ++i;
+        size_t j = i;
+        while (j < line.size() && !std::isspace((unsigned char)line[j])) ++j;
+        if (j > i) tok.push_back(line.substr(i, j - i));
+        i = j;
+    }
+    *repeat = 1;
+    size_t k = 0;
+    if (!tok.empty() && std::isdigit((unsigned char)tok[0][0]) && tok[0].find_first_not_of("0123456789") == std::string::npos) {
+        *repeat = std::atoi(tok[0].c_str());
+        k = 1;
+    }
+    InputSystem::clearInputs();
+    for (; k < tok.size(); ++k) {
+        const std::string& t = tok[k];
+        if (t[0] == '#') break;
+        if (t == "d") InputSystem::movementInput.x = 1.0f;        // keyCode 2
+        else if (t == "a") InputSystem::movementInput.x = -1.0f;  // keyCode 0
+        else if (t == "space") InputSystem::movementInput.y = 1.0f;   // keyCode 49
+        else if (t == "c") InputSystem::movementInput.y = -1.0f;      // keyCode 8
+        else if (t == "w") InputSystem::movementInput.z = 1.0f;   // keyCode 13
+        else if (t == "s") InputSystem::movementInput.z = -1.0f;  // keyCode 1
+        else if (t == "r") InputSystem::resetInput = true;        // keyCode 15
+        else if (t == "mouse" && k + 2 < tok.size()) {
+            InputSystem::rotationInput.x = (float)std::atof(tok[k + 1].c_str());
+            InputSystem::rotationInput.y = (float)std::atof(tok[k + 2].c_str());
+            k += 2;
+        } else if (t == "scroll" && k + 1 < tok.size()) {
+            InputSystem::zoomInput = -(float)std::atof(tok[k + 1].c_str());
+            k += 1;
+        } else {
+            std::fprintf(stderr, "camera path: unknown token '%s'\n", t.c_str());
+            return false;
+        }
+    }
+    return true;
+}
+
+// Replays a camera path: one draw() per frame with that frame's inputs, every frame written to outDir.  Returns the
+// number of frames, -1 on error.  Prints one JSON line per frame (camera, frameCount) for checking against the reference's
+// protocol (a camera change resets the accumulation and reseeds, R/Renderer/Renderer.cpp:255-257).
+static int playCameraPath(Renderer& r, OffscreenView& view, const std::string& path, const std::string& outDir) {
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) {
+        std::fprintf(stderr, "cannot open camera path %s\n", path.c_str());
+        return -1;
+    }
+    std::string cmd = "mkdir -p '" + outDir + "'";
+    if (std::system(cmd.c_str()) != 0) std::fprintf(stderr, "cannot create %s\n", outDir.c_str());
+    char buf[512];
+    int frame = 0;
+    while (std::fgets(buf, sizeof buf, f)) {
+        std::string line(buf);
+        size_t h = line.find('#');
+        if (h != std::string::npos) line.erase(h);
+        if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;
+        int repeat = 1;
+        for (int k = 0, n = 1; k < n; ++k) {
+            if (!applyInputLine(line, &repeat)) {
+                std::fclose(f);
+                return -1;
+            }
+            n = repeat;
+            r.draw(&view);
+            r.readFrame(&view);
+            const mpt_uniforms& u = r.uniforms();
+            char name[64];
+            std::snprintf(name, sizeof name, "/frame_%04d.ppm", frame);
+            if (mpt_write_ppm((outDir + name).c_str(), view.rgba.data(), (int)view.width, (int)view.height, 1.0f, 2.2f))
+                std::fprintf(stderr, "cannot write %s%s\n", outDir.c_str(), name);
+            std::printf("{\"frame\": %d, \"frameCount\": %llu, \"camera\": [%.9g, %.9g, %.9g], \"forward\": [%.9g, %.9g, %.9g], \"vfov\": %.9g}\n",
+                        frame, (unsigned long long)u.frameCount, u.cameraPosition[0], u.cameraPosition[1], u.cameraPosition[2],
+                        Camera::forward.x, Camera::forward.y, Camera::forward.z, Camera::verticalFov);
+            ++frame;
+        }
+    }
+    std::fclose(f);
+    return frame;
+}
+
+// Batch render on N GPUs driven by this one host thread (SURVEY.md 8e / include/mpt.h "multi-GPU"): every GPU gets the
+// scene, renders its interleaved tile shard asynchronously, and ONE ncclReduce(sum) lands the HDR sum on the first GPU.
+static int renderOnSeveralGpus(const std::string& scene, const std::string& assetRoot, const std::string& out, int width, int height,
+                               int spp, int device, int gpus, mpt_render_params prm, const float* camPos, const float* camDir,
+                               const float* camUp, float vfov) {
+    std::vector<std::unique_ptr<Renderer>> rs;
+    mpt_comm* comm = nullptr;
+    try {
+        for (int g = 0; g < gpus; ++g) rs.emplace_back(new Renderer(device + g, scene, assetRoot));
+        if (camPos) Camera::position = mpt::float3(camPos[0], camPos[1], camPos[2]);
+        if (camDir) Camera::forward = mpt::normalize(mpt::float3(camDir[0], camDir[1], camDir[2]));
+        if (camUp) Camera::up = mpt::normalize(mpt::float3(camUp[0], camUp[1], camUp[2]));
+        if (vfov > 0.0f) Camera::verticalFov = vfov;
+        std::vector<mpt_ctx*> ctxs;
+        OffscreenView view;
+        for (int g = 0; g < gpus; ++g) {
+            rs[g]->drawableSizeWillChange(&view, DrawableSize{(double)width, (double)height});
+            rs[g]->clearSum();
+            ctxs.push_back(rs[g]->context());
+        }
+        int rc = mpt_comm_create_all(ctxs.data(), gpus, &comm);
+        if (rc) throw std::runtime_error(std::string("mpt_comm_create_all: ") + mpt_last_error(ctxs[0]));
+        auto t0 = std::chrono::steady_clock::now();
+        for (int g = 0; g < gpus; ++g) {  // enqueue everywhere first: mpt_render_async returns at once
+            mpt_render_params p = prm;
+            p.sample_begin = 0;
+            p.sample_count = (uint32_t)spp;
+            p.shard_rank = g;
+            p.shard_count = gpus;
+            mpt_uniforms u = rs[g]->uniforms();
+            u.primitiveCount = rs[g]->scene()->getPrimitiveCount();
+            u.triangleCount = rs[g]->scene()->getTriangleCount();
+            if ((rc = mpt_set_uniforms(ctxs[g], &u)) || (rc = mpt_render_async(ctxs[g], &p)))
+                throw std::runtime_error(std::string("render on GPU ") + std::to_string(device + g) + ": " + mpt_last_error(ctxs[g]));
+        }
+        if ((rc = mpt_reduce_sum(comm, 0))) throw std::runtime_error(std::string("mpt_reduce_sum: ") + mpt_comm_last_error(comm));
+        double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        unsigned long long rays = 0, paths = 0;
+        for (int g = 0; g < gpus; ++g) {
+            mpt_stats st = rs[g]->stats();
+            rays += st.rays;
+            paths += st.paths;
+        }
+        std::printf("{\"gpus\": %d, \"paths\": %llu, \"rays\": %llu, \"seconds\": %.6f, \"mrays_per_s\": %.1f}\n", gpus, paths, rays, sec,
+                    sec > 0 ? rays / sec / 1e6 : 0.0);
+        if (!out.empty()) {
+            std::vector<float> img;
+            rs[0]->readSum(img);
+            bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
+            const float scale = 1.0f / (float)spp;
+            if (ppm ? mpt_write_ppm(out.c_str(), img.data(), width, height, scale, 2.2f) : mpt_write_pfm(out.c_str(), img.data(), width, height, scale))
+                throw std::runtime_error("cannot write " + out);
+        }
+        mpt_comm_destroy(comm);
+        return 0;
+    } catch (const std::exception& e) {
+        if (comm) mpt_comm_destroy(comm);
+        std::fprintf(stderr, "mpt_render: %s\n", e.what());
+        return 1;
+    }
 }
 
 int main(int argc, char** argv) {
-    std::string scene, assetRoot, out;
-    int width = 1280, height = 720, spp = 64, depth = 32, device = 0, frames = 0;
+    std::string scene, assetRoot, out, cameraPath, outDir = "runs";
+    int width = 1280, height = 720, spp = 64, depth = 32, device = 0, frames = 0, gpus = 1;
     unsigned seed = 1;
     float camPos[3], camDir[3], camUp[3], vfov = 0.0f;
     bool havePos = false, haveDir = false, haveUp = false;
@@ -52,6 +210,9 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = static_cast<unsigned>(std::strtoul(next(), nullptr, 10));
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--gpus") gpus = std::atoi(next());
+        else if (a == "--camera-path") cameraPath = next();
+        else if (a == "--out-dir") outDir = next();
         else if (a == "--out") out = next();
         else if (a == "--camera-pos" || a == "--camera-dir" || a == "--camera-up") {
             float v[3] = {0, 0, 0};
@@ -83,6 +244,8 @@ int main(int argc, char** argv) {
     }
     prm.max_depth = depth;
     prm.seed_lo = seed;
+    if (gpus > 1) return renderOnSeveralGpus(scene, assetRoot, out, width, height, spp, device, gpus, prm, havePos ? camPos : nullptr,
+                                             haveDir ? camDir : nullptr, haveUp ? camUp : nullptr, vfov);
     try {
         Renderer r(device, scene, assetRoot);
         r.setRenderParams(prm);
@@ -96,7 +259,13 @@ int main(int argc, char** argv) {
         std::vector<float> img;
         float scale = 1.0f;
         auto t0 = std::chrono::steady_clock::now();
-        if (frames > 0) {
+        if (!cameraPath.empty()) {
+            const int n = playCameraPath(r, view, cameraPath, outDir);
+            if (n < 0) return 1;
+            frames = n;
+            r.readFrame(&view);
+            img = view.rgba;
+        } else if (frames > 0) {
             for (int f = 0; f < frames; ++f) r.draw(&view);
             r.readFrame(&view);
             img = view.rgba;

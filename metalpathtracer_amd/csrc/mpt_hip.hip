@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <exception>
 #include <string>
 #include <vector>
@@ -24,6 +25,7 @@
 #include "mpt_device.h"
 
 #include "mpt_kernels.h"
+#include "mpt_lbvh.h"
 #include "mpt_ordered.h"
 
 // =====================================================================================================
@@ -1218,8 +1220,8 @@ static int render_async_impl(mpt_ctx* ctx, const mpt_render_params* p) {
         return rc;
     Lane& L = ctx->lane[ctx->next_lane];
     if (L.in_flight && (rc = collect_lane(ctx, L))) return rc;
-    ctx->next_lane ^= 1;
     HIPCHK(hipEventRecord(L.ev0, L.stream));
+    ctx->next_lane ^= 1;
     const uint32_t tiles = ((ctx->W + 7) / 8) * ((ctx->H + 7) / 8);
     const uint32_t local_tiles = (tiles + p->shard_count - 1) / p->shard_count;
     uint32_t s_max = (uint32_t)std::max<uint64_t>(
@@ -1233,31 +1235,51 @@ static int render_async_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     }
     const char* e = getenv("MPT_PASS_SPP");
     if (e && atoi(e) > 0) s_max = std::min<uint32_t>(s_max, (uint32_t)atoi(e));
+    // a render that fails half way: drain what it has enqueued, forget its event pairs and give the lane back, so that
+    // the next render starts from a clean lane (the HDR sum may hold some of this render's passes: the caller clears it)
+    auto abandon = [&](int code) {
+        hipStreamSynchronize(L.stream);
+        L.pending_timed.clear();
+        L.ev_used = 0;
+        L.timed = false;
+        L.in_flight = false;
+        ctx->next_lane ^= 1;
+        return code;
+    };
+#define HIPCHK_AB(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return abandon(MPT_ERR_HIP);                                                    \
+        }                                                                                   \
+    } while (0)
     uint32_t done = 0;
     while (done < p->sample_count) {
         uint32_t S = std::min(s_max, p->sample_count - done);
         PassParams pp;
         uint32_t nlt = 0;
         rc = run_pass(ctx, L, p, p->sample_begin + done, S, pp, nlt, ctx->time_kernels);
-        if (rc) return rc;
+        if (rc) return abandon(rc);
         if (nlt) {
             // sum[p] += pass total must happen in submission order on both lanes (float addition does not commute
             // bit for bit): this resolve waits for the previous one, wherever it ran
-            if (ctx->last_resolved) HIPCHK(hipStreamWaitEvent(L.stream, ctx->last_resolved, 0));
+            if (ctx->last_resolved) HIPCHK_AB(hipStreamWaitEvent(L.stream, ctx->last_resolved, 0));
             uint32_t threads = nlt * 64u;
             hipLaunchKernelGGL(k_resolve_sum, dim3((threads + 255) / 256), dim3(256), 0, L.stream, pp, ctx->d_sum, nlt);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(L.ev_resolved, L.stream));
+            HIPCHK_AB(hipGetLastError());
+            HIPCHK_AB(hipEventRecord(L.ev_resolved, L.stream));
             ctx->last_resolved = L.ev_resolved;
         }
         done += S;
         // the next pass reuses the lane's slot buffer and descriptor: in-stream order is enough, no host sync here
     }
-    HIPCHK(hipEventRecord(L.ev1, L.stream));
+    HIPCHK_AB(hipEventRecord(L.ev1, L.stream));
     L.timed = true;
-    if ((rc = enqueue_stats_copy(ctx, L))) return rc;
+    if ((rc = enqueue_stats_copy(ctx, L))) return abandon(rc);
     L.in_flight = true;
     return MPT_OK;
+#undef HIPCHK_AB
 }
 
 static int render_impl(mpt_ctx* ctx, const mpt_render_params* p) {
@@ -1499,6 +1521,21 @@ extern "C" int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]) {
     return MPT_OK;
 }
 
+extern "C" int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims, float* bvh_out, uint64_t bvh_capacity_nodes,
+                             uint64_t* n_nodes_out, int32_t* prim_idx_out, double* device_ms_out) {
+    return guarded(ctx, [&]() -> int {
+        if (!ctx || !prims || !bvh_out || !n_nodes_out || !prim_idx_out || n_prims == 0 || n_prims >= (1ull << 27))
+            return fail(ctx, MPT_ERR_INVALID_ARG, "bad argument");
+        if (bvh_capacity_nodes < 2 * n_prims - 1) return fail(ctx, MPT_ERR_INVALID_ARG, "bvh_out must hold 2 * n_prims - 1 nodes");
+        HIPCHK(hipSetDevice(ctx->device));
+        float ms = 0.0f;
+        hipError_t e = mpt_lbvh::build(ctx->stream, prims, (uint32_t)n_prims, bvh_out, n_nodes_out, prim_idx_out, &ms);
+        if (e != hipSuccess) return fail(ctx, MPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
+        if (device_ms_out) *device_ms_out = ms;
+        return MPT_OK;
+    });
+}
+
 extern "C" int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* h, float* f) {
     return guarded(ctx, [&] { return kat_pcg_impl(ctx, seeds, n, h, f); });
 }
@@ -1509,6 +1546,164 @@ extern "C" int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* c, const uint32_t* k
 
 extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s, float* c) {
     return guarded(ctx, [&] { return kat_sincos_impl(ctx, u, n, s, c); });
+}
+
+// ---- multi-GPU: RCCL reduce of the HDR sum (include/mpt.h) ----------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static const char* rccl_load() {  // nullptr = ok, else what failed
+    if (g_rccl.lib) return nullptr;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return "librccl.so not found";
+    RcclApi a;
+    a.lib = h;
+#define MPT_SYM(field, name)                                 \
+    *(void**)(&a.field) = dlsym(h, name);                    \
+    if (!a.field) {                                          \
+        dlclose(h);                                          \
+        return "librccl.so lacks " name;                     \
+    }
+    MPT_SYM(GetUniqueId, "ncclGetUniqueId")
+    MPT_SYM(CommInitAll, "ncclCommInitAll")
+    MPT_SYM(CommInitRank, "ncclCommInitRank")
+    MPT_SYM(CommDestroy, "ncclCommDestroy")
+    MPT_SYM(Reduce, "ncclReduce")
+    MPT_SYM(GroupStart, "ncclGroupStart")
+    MPT_SYM(GroupEnd, "ncclGroupEnd")
+    MPT_SYM(GetErrorString, "ncclGetErrorString")
+#undef MPT_SYM
+    g_rccl = a;
+    return nullptr;
+}
+}  // namespace
+static_assert(sizeof(ncclUniqueId) == MPT_COMM_ID_BYTES, "MPT_COMM_ID_BYTES must match ncclUniqueId");
+
+struct mpt_comm {
+    std::vector<mpt_ctx*> ctxs;      // local contexts (all N in one process, or this rank's one)
+    std::vector<ncclComm_t> comms;   // one per local context; empty when nranks == 1
+    int nranks = 1, first_rank = 0;  // global size; global rank of ctxs[0]
+    std::string err;
+};
+
+extern "C" const char* mpt_comm_last_error(const mpt_comm* c) { return c ? c->err.c_str() : "null communicator"; }
+
+extern "C" int mpt_comm_unique_id(void* id_out) {
+    if (!id_out) return MPT_ERR_INVALID_ARG;
+    if (rccl_load()) return MPT_ERR_HIP;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return MPT_ERR_HIP;
+    memcpy(id_out, &id, sizeof id);
+    return MPT_OK;
+}
+
+extern "C" int mpt_comm_create_all(mpt_ctx* const* ctxs, int n, mpt_comm** out) {
+    if (!out) return MPT_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!ctxs || n < 1) return MPT_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return MPT_ERR_INVALID_ARG;
+    try {
+        std::unique_ptr<mpt_comm> c(new mpt_comm());
+        c->ctxs.assign(ctxs, ctxs + n);
+        c->nranks = n;
+        if (n > 1) {
+            if (const char* why = rccl_load()) return fail(ctxs[0], MPT_ERR_HIP, why);
+            std::vector<int> devs(n);
+            for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+            c->comms.resize(n);
+            ncclResult_t r = g_rccl.CommInitAll(c->comms.data(), n, devs.data());
+            if (r != ncclSuccess) return fail(ctxs[0], MPT_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+        }
+        *out = c.release();
+        return MPT_OK;
+    } catch (...) {
+        return MPT_ERR_HIP;
+    }
+}
+
+extern "C" int mpt_comm_create_rank(mpt_ctx* ctx, int rank, int nranks, const void* id, mpt_comm** out) {
+    if (!out) return MPT_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id)) return MPT_ERR_INVALID_ARG;
+    try {
+        std::unique_ptr<mpt_comm> c(new mpt_comm());
+        c->ctxs.push_back(ctx);
+        c->nranks = nranks;
+        c->first_rank = rank;
+        if (nranks > 1) {
+            if (const char* why = rccl_load()) return fail(ctx, MPT_ERR_HIP, why);
+            if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, MPT_ERR_HIP, "hipSetDevice failed");
+            ncclUniqueId uid;
+            memcpy(&uid, id, sizeof uid);
+            c->comms.resize(1);
+            ncclResult_t r = g_rccl.CommInitRank(&c->comms[0], nranks, uid, rank);
+            if (r != ncclSuccess) return fail(ctx, MPT_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+        }
+        *out = c.release();
+        return MPT_OK;
+    } catch (...) {
+        return MPT_ERR_HIP;
+    }
+}
+
+extern "C" int mpt_reduce_sum(mpt_comm* c, int root) {
+    if (!c || root < 0 || root >= c->nranks) return MPT_ERR_INVALID_ARG;
+    // every local context: collect the renders in flight (their resolves have then updated the HDR sum)
+    for (mpt_ctx* ctx : c->ctxs) {
+        int rc = wait_impl(ctx);
+        if (rc) {
+            c->err = ctx->err;
+            return rc;
+        }
+        if (!ctx->d_sum || ctx->W != c->ctxs[0]->W || ctx->H != c->ctxs[0]->H) {
+            c->err = "contexts of a communicator must be sized alike (mpt_resize)";
+            return MPT_ERR_NOT_READY;
+        }
+    }
+    if (c->nranks == 1) return MPT_OK;  // one GPU holds the whole image already
+    const size_t count = (size_t)c->ctxs[0]->W * c->ctxs[0]->H * 4;
+    ncclResult_t r = g_rccl.GroupStart();
+    for (size_t i = 0; i < c->ctxs.size() && r == ncclSuccess; ++i) {
+        mpt_ctx* ctx = c->ctxs[i];
+        if (hipSetDevice(ctx->device) != hipSuccess) r = ncclUnhandledCudaError;
+        else r = g_rccl.Reduce(ctx->d_sum, ctx->d_sum, count, ncclFloat32, ncclSum, root, c->comms[i], ctx->stream);
+    }
+    ncclResult_t e = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) {
+        c->err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r);
+        return MPT_ERR_HIP;
+    }
+    for (mpt_ctx* ctx : c->ctxs) {
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            c->err = "stream synchronisation after ncclReduce failed";
+            return MPT_ERR_HIP;
+        }
+    }
+    return MPT_OK;
+}
+
+extern "C" int mpt_comm_destroy(mpt_comm* c) {
+    if (!c) return MPT_ERR_INVALID_ARG;
+    for (ncclComm_t k : c->comms)
+        if (k && g_rccl.CommDestroy) g_rccl.CommDestroy(k);
+    delete c;
+    return MPT_OK;
 }
 
 #ifdef MPT_DEBUG_WAVE_TIMES

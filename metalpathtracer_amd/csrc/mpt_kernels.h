@@ -12,9 +12,9 @@
 
 #include "mpt_device.h"
 
-// Minimum waves per SIMD the trace kernels are compiled for (2nd __launch_bounds__ argument).  The kernels are
-// latency-bound (dependent LDS / L2 reads per BVH step): 8 waves/SIMD (<= 64 VGPRs, 2 x 1024-thread workgroups
-// per CU next to 2 x 57 KB of LDS) measured faster than 4-5 waves/SIMD at 81-83 VGPRs.
+// Minimum waves per SIMD the two secondary trace kernels (k_step, k_megakernel) are compiled for (2nd __launch_bounds__
+// argument): 8 waves/SIMD (<= 64 VGPRs, 2 x 1024-thread workgroups per CU next to 2 x 57 KB of LDS).  k_wavelocal has
+// its own operating point (MPT_WL_THREADS / MPT_WL_WAVES below: 6 waves/SIMD, 80 VGPRs), k_ordered another (mpt_ordered.h).
 #ifndef MPT_MIN_WAVES
 #define MPT_MIN_WAVES 8
 #endif
@@ -182,9 +182,10 @@ __device__ __forceinline__ void stage_nodes(const SceneDev& sc, float4* lds) {
     __syncthreads();
 }
 
-// Wave-uniform work fetch: a wave claims a run of consecutive 64-slot items from its home group's
-// cursor (then steals from the other groups).  The run length is guided — remaining / (2 * waves) clamped
-// to [1, 16] — so the bulk of an iteration costs few atomics and the tail stays fine-grained.
+// Wave-uniform work fetch of the GLOBAL wavefront (k_step): a wave claims a run of consecutive 64-slot items from its
+// home group's cursor (then steals from the other groups).  The run length is guided — remaining / (2 * waves) clamped
+// to [1, 16] — so the bulk of an iteration costs few atomics and the tail stays fine-grained.  (k_wavelocal / k_ordered
+// claim path ids with remaining / (16 * waves): see the comment at their claim code.)
 // (every lane of the wave is active here, so readfirstlane returns lane 0's value as an SGPR)
 __device__ __forceinline__ void fetch_items(uint32_t* ctr, const uint32_t* s_range_end, uint32_t home,
                                             uint32_t waves_per_group, uint32_t& first, uint32_t& last) {
@@ -349,8 +350,7 @@ __global__ void k_begin_pass(PassDesc* d, uint32_t* ctr, uint32_t total_paths, u
                              volatile uint32_t* host_done, int path_cursors) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (path_cursors) {  // single-launch pipelines: the cursors count path ids, one contiguous range per group
-        d->total_paths = total_paths;
-        d->overflow = 0;
+        d->total_paths = total_paths;  // overflow stays sticky until the host has read it (enqueue_stats_copy clears it)
         for (uint32_t g = 0; g < MPT_NGROUP; ++g) ctr[MPT_CTR_CURSOR(g)] = 0u;
         return;
     }

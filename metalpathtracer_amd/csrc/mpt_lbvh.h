@@ -1,0 +1,289 @@
+// mpt_lbvh.h — BVH construction ON THE GPU: a linear BVH (63-bit Morton codes of the primitive
+// centroids, radix sort, Karras' parallel radix-tree construction, bottom-up refit) collapsed to leaves of <= 8
+// primitives and written in the REFERENCE's buffer format (SURVEY App. D buf 0 / buf 6):
+//   node = (bmin.xyz, bits(leftFirst)) (bmax.xyz, bits(count));  count > 0: leaf, primitiveIndices[leftFirst ..
+//   leftFirst+count);  count <= 0: internal, left child = leftFirst, right child = -count;  root = node 0.
+// It stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,195-317: a sequential
+// full-sweep SAH over std::sort, 8.2 s for 1 M primitives on one core); primitive boxes follow Scene.h:199-209
+// (sphere: centre -+ radius; triangle: min / max of the vertices) and parent boxes are unions of child boxes, so boxes
+// nest exactly (which the closest-first pipeline requires).  The tree topology is not a parity target: the
+// oracle renders the same image from these arrays as the HIP pipelines do (tests/test_gpu_lbvh.py).
+// The quality of the inner nodes hardly matters to the default pipeline: it builds its own 4-wide tree over the LEAVES
+// (mpt_accel.h); what it takes from here is the partition into leaves — Morton-contiguous runs of <= 8 primitives.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#define MPT_LBVH_LEAF 8u
+
+namespace mpt_lbvh {
+
+__device__ __forceinline__ int f2ord(float f) {  // order-preserving float -> int (for atomicMin / atomicMax)
+    int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+// primitive boxes (Scene.h:199-209) + bounds of the box centres
+__global__ void k_boxes(const float4* prims, uint32_t n, float4* blo, float4* bhi, int* cb /* [6]: min xyz, max xyz as ordered ints */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, c[3] = {0, 0, 0};
+    const bool valid = i < n;
+    if (valid) {
+        const float4 p0 = prims[3 * (size_t)i], p1 = prims[3 * (size_t)i + 1], p2 = prims[3 * (size_t)i + 2];
+        if ((int)p0.w == 0) {
+            lo[0] = p0.x - p1.x; lo[1] = p0.y - p1.x; lo[2] = p0.z - p1.x;
+            hi[0] = p0.x + p1.x; hi[1] = p0.y + p1.x; hi[2] = p0.z + p1.x;
+        } else {
+            lo[0] = fminf(p0.x, fminf(p1.x, p2.x)); lo[1] = fminf(p0.y, fminf(p1.y, p2.y)); lo[2] = fminf(p0.z, fminf(p1.z, p2.z));
+            hi[0] = fmaxf(p0.x, fmaxf(p1.x, p2.x)); hi[1] = fmaxf(p0.y, fmaxf(p1.y, p2.y)); hi[2] = fmaxf(p0.z, fmaxf(p1.z, p2.z));
+        }
+        blo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        bhi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        for (int a = 0; a < 3; ++a) c[a] = 0.5f * lo[a] + 0.5f * hi[a];
+    }
+    // wave reduction, then one atomic per wave and component
+    for (int a = 0; a < 3; ++a) {
+        float mn = valid && isfinite(c[a]) ? c[a] : INFINITY, mx = valid && isfinite(c[a]) ? c[a] : -INFINITY;
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            atomicMin(&cb[a], f2ord(mn));
+            atomicMax(&cb[3 + a], f2ord(mx));
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  // 21 bits -> every third bit
+    v &= 0x1FFFFFull;
+    v = (v | v << 32) & 0x1F00000000FFFFull;
+    v = (v | v << 16) & 0x1F0000FF0000FFull;
+    v = (v | v << 8) & 0x100F00F00F00F00Full;
+    v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+__global__ void k_morton(const float4* blo, const float4* bhi, uint32_t n, const int* cb, unsigned long long* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long code = 0;
+    for (int a = 0; a < 3; ++a) {
+        const float mn = ord2f(cb[a]), mx = ord2f(cb[3 + a]);
+        const float lo = a == 0 ? blo[i].x : a == 1 ? blo[i].y : blo[i].z, hi = a == 0 ? bhi[i].x : a == 1 ? bhi[i].y : bhi[i].z;
+        const float c = 0.5f * lo + 0.5f * hi, ext = mx - mn;
+        float u = ext > 0.0f ? (c - mn) / ext : 0.0f;
+        u = isfinite(u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
+        const unsigned long long q = (unsigned long long)fminf(u * 2097152.0f, 2097151.0f);
+        code |= spread21(q) << (2 - a);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+// Karras 2012: internal node i of the radix tree over the sorted keys; ties are broken by position
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)i ^ (unsigned)j);
+    return __clzll((long long)(a ^ b));
+}
+// node ids: internal k in [0, n-1), leaf (single primitive) p -> (n-1) + p
+__global__ void k_hierarchy(const unsigned long long* keys, int n, int2* child, int* parent, int2* range) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int left = lo == gamma ? (n - 1) + gamma : gamma;
+    const int right = hi == gamma + 1 ? (n - 1) + gamma + 1 : gamma + 1;
+    child[i] = make_int2(left, right);
+    range[i] = make_int2(lo, hi);
+    parent[left] = i;
+    parent[right] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+__device__ __forceinline__ float4 ld4(const float4* p) {
+    const float* f = (const float*)p;
+    return make_float4(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0.0f);
+}
+// bottom-up boxes: the second thread to arrive at a node computes it
+__global__ void k_refit(const uint32_t* vals, const float4* blo, const float4* bhi, int n, const int2* child, const int* parent,
+                        float4* nlo, float4* nhi, int* arrived) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t prim = vals[p];
+    nlo[(n - 1) + p] = blo[prim];
+    nhi[(n - 1) + p] = bhi[prim];
+    __threadfence();
+    int node = parent[(n - 1) + p];
+    while (node >= 0) {
+        if (atomicAdd(&arrived[node], 1) == 0) return;  // the sibling subtree is not finished yet
+        __threadfence();
+        const int2 c = child[node];
+        // the sibling's box was written by another CU: read it past this CU's L1 (agent-scope loads)
+        const float4 a0 = ld4(nlo + c.x), a1 = ld4(nhi + c.x), b0 = ld4(nlo + c.y), b1 = ld4(nhi + c.y);
+        nlo[node] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.0f);
+        nhi[node] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.0f);
+        __threadfence();
+        node = parent[node];
+    }
+}
+
+// which radix-tree nodes become nodes of the output: an internal node spanning more than LEAF primitives stays internal;
+// a node (internal or single primitive) spanning <= LEAF primitives whose parent spans more becomes a leaf
+__device__ __forceinline__ int span(const int2* range, int n, int node) { return node >= n - 1 ? 1 : range[node].y - range[node].x + 1; }
+__global__ void k_mark(int n, const int* parent, const int2* range, uint32_t* keep) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= 2 * n - 1) return;
+    const int sz = span(range, n, node), par = parent[node];
+    const bool k = sz > (int)MPT_LBVH_LEAF || par < 0 || span(range, n, par) > (int)MPT_LBVH_LEAF;
+    keep[node] = k ? 1u : 0u;
+}
+__global__ void k_emit(int n, const int2* child, const int2* range, const uint32_t* keep, const uint32_t* index, const float4* nlo,
+                       const float4* nhi, const uint32_t* vals, float4* bvh_out, int* prim_idx_out) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node < n) prim_idx_out[node] = (int)vals[node];  // primitiveIndices = the sorted order
+    if (node >= 2 * n - 1 || !keep[node]) return;
+    const uint32_t at = index[node];
+    const int sz = span(range, n, node);
+    int lf, cnt;
+    if (sz > (int)MPT_LBVH_LEAF) {
+        lf = (int)index[child[node].x];
+        cnt = -(int)index[child[node].y];
+    } else {
+        lf = node >= n - 1 ? node - (n - 1) : range[node].x;
+        cnt = sz;
+    }
+    const float4 lo = nlo[node], hi = nhi[node];
+    bvh_out[2 * (size_t)at] = make_float4(lo.x, lo.y, lo.z, __int_as_float(lf));
+    bvh_out[2 * (size_t)at + 1] = make_float4(hi.x, hi.y, hi.z, __int_as_float(cnt));
+}
+
+struct Scratch {  // freed on every exit path
+    std::vector<void*> ptrs;
+    ~Scratch() {
+        for (void* p : ptrs) hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T** p, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(q);
+        *p = (T*)q;
+        return e;
+    }
+};
+
+// prims: host, 12 floats per primitive (Scene::createTransformsBuffer).  bvh_out: host, room for 8 * (2n - 1) floats;
+// prim_idx_out: host, n ints.  Returns hipSuccess and the node count, or the failing HIP status.
+static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, float* bvh_out, uint64_t* n_nodes_out,
+                        int32_t* prim_idx_out, float* ms_out) {
+#define MPT_LB(call)                       \
+    do {                                   \
+        hipError_t e_ = (call);            \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+    Scratch sc;
+    float4 *d_prims, *blo, *bhi, *nlo, *nhi, *d_bvh;
+    int *cb, *parent, *arrived, *d_idx;
+    int2 *child, *range;
+    unsigned long long *keys, *keys2;
+    uint32_t *vals, *vals2, *keep, *index;
+    const size_t nn = 2 * (size_t)n - 1;
+    MPT_LB(sc.alloc(&d_prims, 3 * (size_t)n));
+    MPT_LB(sc.alloc(&blo, n));
+    MPT_LB(sc.alloc(&bhi, n));
+    MPT_LB(sc.alloc(&nlo, nn));
+    MPT_LB(sc.alloc(&nhi, nn));
+    MPT_LB(sc.alloc(&d_bvh, 2 * nn));
+    MPT_LB(sc.alloc(&cb, 6));
+    MPT_LB(sc.alloc(&parent, nn));
+    MPT_LB(sc.alloc(&arrived, n));
+    MPT_LB(sc.alloc(&d_idx, n));
+    MPT_LB(sc.alloc(&child, n));
+    MPT_LB(sc.alloc(&range, n));
+    MPT_LB(sc.alloc(&keys, n));
+    MPT_LB(sc.alloc(&keys2, n));
+    MPT_LB(sc.alloc(&vals, n));
+    MPT_LB(sc.alloc(&vals2, n));
+    MPT_LB(sc.alloc(&keep, nn + 1));
+    MPT_LB(sc.alloc(&index, nn + 1));
+    MPT_LB(hipMemcpyAsync(d_prims, prims, (size_t)n * 48, hipMemcpyHostToDevice, stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    MPT_LB(hipEventCreate(&e0));
+    hipError_t rc = hipEventCreate(&e1);
+    if (rc != hipSuccess) {
+        hipEventDestroy(e0);
+        return rc;
+    }
+    auto body = [&]() -> hipError_t {
+        const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+        MPT_LB(hipMemcpyAsync(cb, init, sizeof init, hipMemcpyHostToDevice, stream));
+        MPT_LB(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
+        MPT_LB(hipEventRecord(e0, stream));
+        const uint32_t B = 256, gn = (n + B - 1) / B, gnn = (uint32_t)((nn + B - 1) / B);
+        hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, blo, bhi, cb);
+        hipLaunchKernelGGL(k_morton, dim3(gn), dim3(B), 0, stream, (const float4*)blo, (const float4*)bhi, n, (const int*)cb, keys, vals);
+        size_t tmp_bytes = 0;
+        MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, stream));
+        char* tmp;
+        MPT_LB(sc.alloc(&tmp, tmp_bytes));
+        MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, stream));
+        if (n > 1) {
+            hipLaunchKernelGGL(k_hierarchy, dim3(gn), dim3(B), 0, stream, (const unsigned long long*)keys2, (int)n, child, parent, range);
+        } else {
+            const int minus1 = -1;
+            MPT_LB(hipMemcpyAsync(parent, &minus1, 4, hipMemcpyHostToDevice, stream));
+        }
+        hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, stream, (const uint32_t*)vals2, (const float4*)blo, (const float4*)bhi, (int)n,
+                           (const int2*)child, (const int*)parent, nlo, nhi, arrived);
+        hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, (const int*)parent, (const int2*)range, keep);
+        size_t scan_bytes = 0;
+        MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, index, (int)nn + 1, stream));
+        char* tmp2;
+        MPT_LB(sc.alloc(&tmp2, scan_bytes));
+        MPT_LB(hipMemsetAsync(keep + nn, 0, 4, stream));
+        MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, scan_bytes, keep, index, (int)nn + 1, stream));
+        hipLaunchKernelGGL(k_emit, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child, (const int2*)range, (const uint32_t*)keep,
+                           (const uint32_t*)index, (const float4*)nlo, (const float4*)nhi, (const uint32_t*)vals2, d_bvh, d_idx);
+        MPT_LB(hipGetLastError());
+        MPT_LB(hipEventRecord(e1, stream));
+        uint32_t n_out = 0;
+        MPT_LB(hipMemcpyAsync(&n_out, index + nn, 4, hipMemcpyDeviceToHost, stream));
+        MPT_LB(hipStreamSynchronize(stream));
+        MPT_LB(hipMemcpy(bvh_out, d_bvh, (size_t)n_out * 32, hipMemcpyDeviceToHost));
+        MPT_LB(hipMemcpy(prim_idx_out, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
+        *n_nodes_out = n_out;
+        if (ms_out) MPT_LB(hipEventElapsedTime(ms_out, e0, e1));
+        return hipSuccess;
+    };
+    rc = body();
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+#undef MPT_LB
+}
+
+}  // namespace mpt_lbvh

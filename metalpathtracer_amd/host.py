@@ -14,7 +14,7 @@ from . import capi
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmpt_host.so")
 
-BVH_REFERENCE_SWEEP, BVH_BINNED_CENTROID = 0, 1
+BVH_REFERENCE_SWEEP, BVH_BINNED_CENTROID, BVH_GPU_LBVH = 0, 1, 2
 
 SYMBOLS = (
     "mpt_scene_create", "mpt_scene_destroy", "mpt_scene_clear", "mpt_scene_load_xml", "mpt_scene_add_primitive",

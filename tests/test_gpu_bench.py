@@ -31,8 +31,15 @@ def test_bench_line_single_gpu():
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Mrays/s" and d["value"] > 0
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["launches"] == 2
+    # a bound that binds: vector-ALU issue or measured HBM traffic, whichever is larger — never above 1
+    assert rf["bound"] in ("valu", "hbm") and rf["launches"] == 2 and rf["kernel"] == "k_ordered"
+    if rf["frac"] is not None:      # a counter profile of this pipeline is committed under profiles/
+        assert 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+        assert rf["frac"] == max(rf["valu"]["frac"], rf["hbm"]["frac"])
+        assert rf["hbm"]["peak"] == 8000.0 and 0.0 < rf["valu"]["lane_utilisation"] <= 1.0
+        assert rf["traffic"] > 0 and "profiles/" in rf["source"]
+    assert rf["algorithmic"]["bytes_per_ray"] > 168.0
+    assert d["serial_ms_per_render"] > 0 and d["config"]["serial_mrays_per_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
     assert d["config"]["paths"] == 640 * 360 * 8 * 2

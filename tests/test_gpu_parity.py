@@ -556,11 +556,11 @@ def test_production_kernel_variant_bit_exact(gpu_ctx, name, W, H, cam, depth, sp
 
 def test_randomised_cases_bit_exact():
     """60 random (scene, size, sample range, depth, seed, BSDF mode, pipeline, shard count, sync/async) cases, each
-    compared bit for bit with the oracle (tools/gpu_fuzz_parity.py)."""
+    compared bit for bit with the oracle (tests/gpu_fuzz_parity.py)."""
     import os, subprocess, sys
     from conftest import ROOT
     env = dict(os.environ, CASES="60", SEED="3")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz_parity.py")], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_fuzz_parity.py")], capture_output=True, text=True,
                        timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "60 cases, 0 mismatches" in r.stdout
@@ -568,10 +568,10 @@ def test_randomised_cases_bit_exact():
 
 def test_headline_config_is_bit_identical_to_the_oracle():
     """BASELINE.json configs[1] itself — scene.xml, 1920x1080, 256 spp, depth 8 (890,385,105 rays): every float of the
-    HDR sum equals the oracle's (tools/gpu_headline_parity.py; the oracle takes ~8 s on the GPU box's 16 host threads)."""
+    HDR sum equals the oracle's (tests/gpu_headline_parity.py, default pipeline = closest-first; the oracle takes ~8 s on the GPU box's 16 host threads)."""
     import os, subprocess, sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_headline_parity.py")], capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_headline_parity.py")], capture_output=True,
                        text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "bit-identical=True" in r.stdout and "890385105 rays" in r.stdout
