@@ -150,6 +150,9 @@ struct WorkCount {
     unsigned long long t_box, t_leaf;              // diagnostics build: shader-clock cycles spent in the two loops
     uint32_t wait_leaf, wait_done;                 // box-loop trips this lane idled holding a leaf / after finishing
 #endif
+#ifdef MPT_OT_TIMES
+    unsigned long long ot_node_cycles, ot_leaf_cycles, ot_node_trips, ot_leaf_trips, ot_rounds;  // closest-first walk, per wave
+#endif
 };
 #ifdef MPT_DEBUG_WAVE_TIMES
 #define MPT_TIC(var) unsigned long long var = __builtin_amdgcn_s_memtime()

@@ -50,6 +50,18 @@ static WaveBudgets default_budgets() {
     return w;
 }
 
+// Node-loop trips a step of tree-walk ring M_k may make before its unfinished rays are parked in M_k+1 (MPT_OT_BUDGETS),
+// and the number of lanes that must still be walking for a step to go on (MPT_OT_MIN_ACTIVE).
+static OtBudgets default_ot_budgets() {
+    OtBudgets b;
+    const uint32_t ladder[] = {12, 32, 80, 200, 500};  // measured on scene.xml / bunny x20: 4,10 -> 29.3 / 123 ms, 12,32 -> 28.1 / 113, 24,64 -> 28.4 / 115
+    for (uint32_t k = 0; k < MPT_OT_MLEVELS; ++k) {
+        b.trips[k] = k + 1 < MPT_OT_MLEVELS && k < 5 ? ladder[k] : 0x7FFFFFFFu;
+        b.min_active[k] = k == 0 ? 0 : 24;
+    }
+    return b;
+}
+
 struct Lane {
     hipStream_t stream = nullptr;
     QueueDev q[2] = {};
@@ -66,8 +78,8 @@ struct Lane {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_timed;  // kernel-event pairs to read at collection
     WaveRings ring = {};         // wave-local pipeline: MPT_WL_LEVELS rings of MPT_WL_RING records per wave
     size_t ring_waves = 0;
-    uint2* d_ot_spill = nullptr; // closest-first pipeline: stack entries beyond the LDS part, per wave
-    size_t ot_spill_waves = 0;
+    OtRings ot_ring = {};        // ... and its rings (MPT_OT_RINGS per wave)
+    size_t ot_ring_waves = 0;
     bool in_flight = false;      // enqueued by mpt_render_async, not yet collected
     bool timed = false;
 };
@@ -93,7 +105,7 @@ struct mpt_ctx {
     float4* d_always = nullptr;
     uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, ot_lds_nodes = 0, ot_lds_prims = 0;
     uint32_t ot_stack_depth = 8;     // LDS stack entries per lane (MPT_OT_STACK); deeper entries spill to global memory
-    uint32_t ot_walk_now_min = 24;   // a primary / fresh-ray step walks the tree at once when this many lanes need it
+    OtBudgets ot_budgets = default_ot_budgets();
     float tri_extent = 0.0f, acc_eps_abs = 0.0f;
     bool acc_ok = false;             // the closest-first pipeline may be used for this scene
     std::string acc_why;
@@ -139,7 +151,10 @@ static const void* mega_kernel(bool count, bool all_lds) {
     return all_lds ? (const void*)k_megakernel<false, true> : (const void*)k_megakernel<false, false>;
 }
 
-static const void* ordered_kernel(bool count) { return count ? (const void*)k_ordered<true> : (const void*)k_ordered<false>; }
+static const void* ordered_kernel(bool count, bool all_lds) {
+    if (count) return all_lds ? (const void*)k_ordered<true, true> : (const void*)k_ordered<true, false>;
+    return all_lds ? (const void*)k_ordered<false, true> : (const void*)k_ordered<false, false>;
+}
 
 static const void* wavelocal_kernel(bool count, bool all_lds) {
     if (count) return all_lds ? (const void*)k_wavelocal<true, true> : (const void*)k_wavelocal<true, false>;
@@ -251,8 +266,20 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
     if ((e = getenv("MPT_WL_MIN")) && atoi(e) >= 64) ctx->wl_min = (uint32_t)atoi(e) & ~63u;
     if ((e = getenv("MPT_TILE_ORDER"))) ctx->tile_order_mode = atoi(e);
     if ((e = getenv("MPT_WL_DIV")) && atoi(e) >= 1) ctx->wl_div = (uint32_t)atoi(e);
-    if ((e = getenv("MPT_OT_STACK")) && atoi(e) >= 2 && atoi(e) <= 12) ctx->ot_stack_depth = (uint32_t)atoi(e);
-    if ((e = getenv("MPT_OT_WALK_NOW")) && atoi(e) >= 1 && atoi(e) <= 65) ctx->ot_walk_now_min = (uint32_t)atoi(e);
+    if ((e = getenv("MPT_OT_STACK")) && atoi(e) >= 2 && atoi(e) <= (int)MPT_OT_PARK) ctx->ot_stack_depth = (uint32_t)atoi(e);
+    for (int which = 0; which < 2; ++which)
+        if ((e = getenv(which ? "MPT_OT_MIN_ACTIVE" : "MPT_OT_BUDGETS"))) {  // "a,b,c": one number per tree-walk ring
+            const char* q = e;
+            for (uint32_t k = 0; k < MPT_OT_MLEVELS && q; ++k) {
+                unsigned v = 0;
+                int used = 0;
+                if (sscanf(q, "%u%n", &v, &used) != 1) break;
+                q += used;
+                if (*q == ',') ++q;
+                if (which) ctx->ot_budgets.min_active[k] = v > 64 ? 64 : v;
+                else if (k + 1 < MPT_OT_MLEVELS) ctx->ot_budgets.trips[k] = v < 1 ? 1 : v;
+            }
+        }
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 0;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
@@ -262,13 +289,19 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
             hipFuncSetAttribute(mega_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute(wavelocal_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
-    for (int c = 0; c < 2; ++c) hipFuncSetAttribute(ordered_kernel(c), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < 2; ++a) hipFuncSetAttribute(ordered_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_trace_rays_ordered, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return MPT_OK;
 }
 
+static void free_ot_rings(OtRings& r) {
+    hipFree(r.od); hipFree(r.dt); hipFree(r.tl); hipFree(r.ia); hipFree(r.tv);
+    for (auto& p : r.sk) hipFree(p);
+    r = OtRings{};
+}
 static void free_queues(Lane& L) {
     for (int i = 0; i < 2; ++i) {
         hipFree(L.q[i].od);
@@ -305,7 +338,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
         hipFree(L.ring.tl);
         hipFree(L.ring.ia);
         hipFree(L.ring.tv);
-        hipFree(L.d_ot_spill);
+        free_ot_rings(L.ot_ring);
         free_queues(L);
         if (L.h_done) hipHostFree(L.h_done);
         if (L.h_desc) hipHostFree(L.h_desc);
@@ -587,10 +620,14 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         for (size_t i = 0; i < dprims.size() / 12; ++i) {
             const float* r = dprims.data() + i * 12;
             if (bits_to_int(r[3]) & 1) continue;
-            float rec[12];
+            float rec[20];
             memcpy(rec, r, 48);
+            const uint32_t k = (uint32_t)(always.size() / 20), leaf = (uint32_t)bits_to_int(r[3]) >> 1;
             rec[5] = int_to_bits((int)i);  // own position in the primitive array = what the walk reports as the winner
-            always.insert(always.end(), rec, rec + 12);
+            rec[6] = int_to_bits((int)k);
+            memcpy(rec + 12, refleaf.data() + 8 * (size_t)leaf, 32);  // the box of its reference leaf, for the final check
+            always.insert(always.end(), rec, rec + 20);
+            dprims[i * 12 + 6] = int_to_bits((int)k);  // the primitive record points back at its always-list entry
         }
 
     // 5. reference-order structure: breadth-first permutation of the threaded nodes (top of the tree first -> LDS).
@@ -651,12 +688,12 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     HIPCHK(up(&ctx->d_mats, mat_table, 8));
     HIPCHK(up(&ctx->d_acc_nodes, acc_nodes, MPT_ACCEL_NODE_FLOATS));
     HIPCHK(up(&ctx->d_refleaf, refleaf, 8));
-    HIPCHK(up(&ctx->d_always, always, 12));
+    HIPCHK(up(&ctx->d_always, always, 20));
     ctx->n_nodes = ND;
     ctx->n_prims = (uint32_t)(dprims.size() / 12);
     ctx->n_mats = (uint32_t)(mat_table.size() / 8);
     ctx->n_acc_nodes = (uint32_t)(acc_nodes.size() / MPT_ACCEL_NODE_FLOATS);
-    ctx->n_always = (uint32_t)(always.size() / 12);
+    ctx->n_always = (uint32_t)(always.size() / 20);
     ctx->n_ref_leaves = (uint32_t)(refleaf.size() / 8);
     ctx->acc_depth = topo.depth;
     ctx->tri_extent = tri_extent;
@@ -675,16 +712,19 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         ctx->n_lds_prims = (uint32_t)(prim_bytes / 48);
         ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ND, (budget - prim_bytes) / 32);
     }
-    // LDS image of the closest-first kernel (one 1024-thread workgroup per CU): the stacks, then as many own nodes as
-    // fit (breadth-first prefix), the always list, and primitives with what is left (at least 4 KiB of them).
+    // LDS image of the closest-first kernel (MPT_OT_WGS_PER_CU workgroups of MPT_OT_THREADS share a CU's 160 KiB): the
+    // stacks, then as many own nodes as fit (breadth-first prefix), the always list, and primitives with what is left.
     {
         const size_t stacks = (size_t)MPT_OT_THREADS * ctx->ot_stack_depth * 8;
-        const size_t total = 160 * 1024 - MPT_LDS_EXTRA - stacks - (size_t)ctx->n_always * 48;
+        // (two workgroups per CU get 78 KiB each, not 80: the allocation granule must leave both room)
+        const size_t avail = MPT_OT_WGS_PER_CU == 1 ? 160 * 1024 : 156 * 1024 / MPT_OT_WGS_PER_CU, fixed = MPT_LDS_EXTRA + stacks + (size_t)ctx->n_always * 80;
+        const size_t total = avail > fixed + 112 ? avail - fixed : 112;
         const size_t all_nodes = (size_t)ctx->n_acc_nodes * 112, all_prims = (size_t)ctx->n_prims * 48;
         size_t prim_bytes = all_nodes <= total ? std::min(all_prims, total - all_nodes)
                                                : std::min<size_t>(all_prims, std::min<size_t>(4 * 1024, total / 4));
         prim_bytes -= prim_bytes % 48;
         ctx->ot_lds_prims = (uint32_t)(prim_bytes / 48);
+        if (const char* e = getenv("MPT_OT_LDS_PRIMS")) ctx->ot_lds_prims = std::min<uint32_t>(ctx->ot_lds_prims, (uint32_t)atoi(e));
         ctx->ot_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
     }
     ctx->have_scene = true;
@@ -812,12 +852,11 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     a.nodes = ctx->d_acc_nodes;
     a.refleaf = ctx->d_refleaf;
     a.always = ctx->d_always;
-    a.spill = nullptr;
     a.n_nodes = ctx->n_acc_nodes;
     a.n_lds_nodes = ctx->ot_lds_nodes;
     a.n_always = ctx->n_always;
     a.lds_always_off = 7u * a.n_lds_nodes;
-    s.lds_prim_off = a.lds_always_off + 3u * a.n_always;
+    s.lds_prim_off = a.lds_always_off + 5u * a.n_always;
     s.lds_mat_off = s.lds_prim_off + 3u * s.n_lds_prims;
     const uint32_t image4 = s.lds_mat_off + 2u * s.n_lds_mats;
     a.lds_stack_off = image4 * 16u;
@@ -826,16 +865,6 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     a.o_limit = ctx->tri_extent > 0.0f ? 64.0f * ctx->tri_extent : INFINITY;  // no triangles: no tree, nothing to bound
     return (size_t)a.lds_stack_off + (size_t)threads * stack_depth * 8u;
 }
-static int ensure_spill(mpt_ctx* ctx, uint2** spill, size_t* have, size_t waves) {
-    if (waves <= *have) return MPT_OK;
-    hipFree(*spill);
-    *spill = nullptr;
-    *have = 0;
-    HIPCHK(hipMalloc(spill, waves * MPT_OT_SPILL * 64u * sizeof(uint2)));
-    *have = waves;
-    return MPT_OK;
-}
-
 // Fragment.metal:29 + Random.h:32-35: per-pixel u32 seed of the literal RNG.  The float sin-hash is
 // chaotic in the last ulp of sin(), so it is evaluated once on the host with the
 // C library's sinf and uploaded; everything downstream is integer hashing on the device.
@@ -1013,7 +1042,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     const bool all_lds = ctx->n_lds_nodes == ctx->n_nodes;
     const void* kfun = pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
                        : pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
-                       : pipeline == MPT_PIPE_ORDERED  ? ordered_kernel(count_flag(p))
+                       : pipeline == MPT_PIPE_ORDERED  ? ordered_kernel(count_flag(p), ctx->ot_lds_nodes == ctx->n_acc_nodes)
                                                         : step_kernel(count_flag(p), all_lds);
     // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel, mpt_ordered.h: 1024)
     const int wg_max = pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : 1024;
@@ -1029,6 +1058,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
         ctx->occ_per_cu = per_cu;
     }
     if (per_cu < 1) return fail(ctx, MPT_ERR_HIP, "kernel does not fit on a CU");
+    if (getenv("MPT_DEBUG_LAUNCH")) fprintf(stderr, "[mpt] pipeline %d: %d workgroups of %d per CU, %zu B of LDS each\n", pipeline, per_cu, wg, lds);
     if (ctx->wgs_per_cu > 0 && per_cu > ctx->wgs_per_cu) per_cu = ctx->wgs_per_cu;
     const int grid = ctx->prop.multiProcessorCount * per_cu;
     hipStream_t st = L.stream;
@@ -1049,7 +1079,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
         }
         if (pipeline == MPT_PIPE_WAVELOCAL || pipeline == MPT_PIPE_ORDERED) {
             const size_t waves = (size_t)grid * (wg / 64);
-            if (waves > L.ring_waves) {
+            if (pipeline == MPT_PIPE_WAVELOCAL && waves > L.ring_waves) {
                 WaveRings& r = L.ring;
                 hipFree(r.od); hipFree(r.dt); hipFree(r.tl); hipFree(r.ia); hipFree(r.tv);
                 r = WaveRings{};
@@ -1064,11 +1094,20 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
             if (pipeline == MPT_PIPE_ORDERED) {
-                int src = ensure_spill(ctx, &L.d_ot_spill, &L.ot_spill_waves, waves);
-                if (src) return src;
-                accel.spill = L.d_ot_spill;
-                uint32_t walk_now = ctx->ot_walk_now_min;
-                void* args[] = {(void*)&pp, (void*)&accel, (void*)&L.ring, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div, (void*)&walk_now};
+                if (waves > L.ot_ring_waves) {
+                    free_ot_rings(L.ot_ring);
+                    L.ot_ring_waves = 0;
+                    const size_t n = waves * MPT_OT_RINGS * MPT_WL_RING;
+                    OtRings& r = L.ot_ring;
+                    HIPCHK(hipMalloc(&r.od, n * 16));
+                    HIPCHK(hipMalloc(&r.dt, n * 16));
+                    HIPCHK(hipMalloc(&r.tl, n * 16));
+                    HIPCHK(hipMalloc(&r.ia, n * 16));
+                    HIPCHK(hipMalloc(&r.tv, n * 16));
+                    for (auto& p : r.sk) HIPCHK(hipMalloc(&p, n * 16));
+                    L.ot_ring_waves = waves;
+                }
+                void* args[] = {(void*)&pp, (void*)&accel, (void*)&L.ot_ring, (void*)&ctx->ot_budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
                 HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
             } else {
                 void* args[] = {(void*)&pp, (void*)&L.ring, (void*)&ctx->budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
@@ -1360,7 +1399,7 @@ static int trace_rays_ordered_impl(mpt_ctx* ctx, const float* o, const float* d,
     if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
     if (!ctx->acc_ok) return fail(ctx, MPT_ERR_BAD_SCENE, "closest-first walk unavailable for this scene: " + ctx->acc_why);
     HIPCHK(hipSetDevice(ctx->device));
-    DevBuf d_o, d_d, d_t, d_n, d_p, d_f, d_g, d_spill;
+    DevBuf d_o, d_d, d_t, d_n, d_p, d_f, d_g;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     HIPCHK(d_o.alloc(n * 12));
     HIPCHK(d_d.alloc(n * 12));
@@ -1369,13 +1408,11 @@ static int trace_rays_ordered_impl(mpt_ctx* ctx, const float* o, const float* d,
     HIPCHK(d_p.alloc(n * 4));
     HIPCHK(d_f.alloc(n * 4));
     HIPCHK(d_g.alloc(n * 4));
-    HIPCHK(d_spill.alloc((size_t)blocks * 4 * MPT_OT_SPILL * 64u * sizeof(uint2)));
     HIPCHK(hipMemcpy(d_o.p, o, n * 12, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_d.p, d, n * 12, hipMemcpyHostToDevice));
     SceneDev sc;
     AccelDev ac;
     const size_t lds = ordered_views(ctx, 256, ctx->ot_stack_depth, sc, ac);
-    ac.spill = (uint2*)d_spill.p;
     hipLaunchKernelGGL(k_trace_rays_ordered, dim3(blocks), dim3(256), lds, ctx->stream, sc, ac, (const float*)d_o.p, (const float*)d_d.p,
                        (uint32_t)n, (float*)d_t.p, (int*)d_p.p, (float*)d_n.p, (int*)d_f.p, (uint32_t*)d_g.p);
     HIPCHK(hipGetLastError());
@@ -1705,6 +1742,19 @@ extern "C" int mpt_comm_destroy(mpt_comm* c) {
     delete c;
     return MPT_OK;
 }
+
+#ifdef MPT_OT_TIMES
+extern "C" int mpt_debug_ot_times(unsigned long long* out32, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_ot_times), 24 * 8);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out32 + 24, HIP_SYMBOL(g_ot_walk), 8 * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[24] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_ot_times), z, sizeof z);
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ot_walk), z, 8 * 8);
+    }
+    return (int)e;
+}
+#endif
 
 #ifdef MPT_DEBUG_WAVE_TIMES
 static mpt_ctx* g_dbg_ctx = nullptr;

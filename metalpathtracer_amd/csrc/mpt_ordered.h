@@ -17,14 +17,18 @@
 // tests/experiments/ordered_proto.cpp replays this rule on the CPU against the oracle: 0 differences in 890 M rays of
 // the headline render (9 of the flagged rays would have differed); the GPU tests compare whole renders bit for bit.
 //
-// Pipeline shape (per persistent wave, rings as in k_wavelocal but sorted by KIND of work instead of by trip budget):
+// Pipeline shape (per persistent wave; rings as in k_wavelocal, but sorted by KIND of work instead of by trip budget, so
+// that every expensive piece of code runs at full width):
 //   primary step   64 new paths: primary rays in registers, TOP TEST = the always-list spheres + the root node's four
-//                  boxes.  94 % of the rays of scene.xml end here (sky, ground, spheres): they are shaded at full
-//                  width; rays that touch a root child are parked in ring M with their (best t, best primitive)
+//                  boxes.  Misses and hits on those spheres are shaded at once; rays that touch a root child go to ring M0
+//                  with their (best t, primitive) so far
 //   ring R step    64 fresh bounce rays: the same
-//   ring M step    64 rays that all have to walk the tree: closest-first walk (LDS stack), final check, shading
-//   ring E step    reference-order walk for the flagged rays (rare)
-// A step whose rays mostly need the tree (camera inside the mesh bounds) walks it at once instead of parking.
+//   ring M_k step  64 rays that all have to walk the tree: closest-first walk (LDS stack) for the ring's budget of node-loop
+//                  trips; unfinished walks are parked in ring M_k+1 with their state (next node, stack, best t /
+//                  primitive): rays sorted by the walk they have behind them meet rays of similar length (lane
+//                  utilisation of the walk 25 % -> 50 %).  Misses are shaded at once, hits go to ring H
+//   ring H step    64 hits in the tree: final check, hit point / normal / material, Philox, BSDF -> bounce rays to ring R
+//   ring E step    reference-order walk + shading for the flagged rays (6.5e-4 of the rays)
 #pragma once
 #include "mpt_device.h"
 #include "mpt_kernels.h"
@@ -38,14 +42,52 @@
 #ifndef MPT_OT_WAVES
 #define MPT_OT_WAVES 4                    // per SIMD: one 1024-thread workgroup per CU, up to 128 VGPRs
 #endif
-#define MPT_OT_SPILL 56u                  // stack entries per lane beyond the LDS part (global memory)
-#define MPT_OT_RINGS 3u                   // R (fresh rays), M (rays that must walk the tree), E (reference-order walk)
+#define MPT_OT_WGS_PER_CU ((MPT_OT_WAVES * 256) / MPT_OT_THREADS)   // workgroups that share a CU's 160 KiB of LDS
+#ifndef MPT_OT_MLEVELS
+#define MPT_OT_MLEVELS 3u                 // tree-walk rings: rays sorted by the walk they have already done (budgets)
+#endif
+#define MPT_OT_RINGS (3u + MPT_OT_MLEVELS) // R fresh rays, H hits to shade, E reference-order walk, M0.. rays walking the tree
+#define MPT_OT_PARK 8u                    // stack entries a parked ray takes along (>= the LDS stack depth)
+#ifndef MPT_OT_EARLY
+#define MPT_OT_EARLY 8u                   // the node loop pauses when fewer than 1/EARLY of the lanes that entered it still search
+#endif
+
+// Diagnostics build (-DMPT_OT_TIMES): shader-clock cycles per region of k_ordered, summed over all waves, plus step and
+// lane counts per step kind (tools/gpu_ot_times.py).  Not compiled into the product library.
+#ifdef MPT_OT_TIMES
+#define OT_NREG 8   // select, fetch, top test, walk, final check, exact walk, shade, push
+__device__ unsigned long long g_ot_walk[8];     // closest-first walk: node-loop cycles, leaf-loop cycles, node trips, leaf trips, rounds
+__device__ unsigned long long g_ot_times[OT_NREG + 16];   // + steps[RINGS + 1] at 8, lanes[RINGS + 1] at 16
+#define OT_TIC() unsigned long long ot_t_ = __builtin_amdgcn_s_memtime()
+#define OT_TOC(r)                                                   \
+    do {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ot_acc[r] += now_ - ot_t_;                                  \
+        ot_t_ = now_;                                               \
+    } while (0)
+#else
+#define OT_TIC() do { } while (0)
+#define OT_TOC(r) do { } while (0)
+#endif
+
+struct OtRings {              // [n_waves][MPT_OT_RINGS][MPT_WL_RING] records, struct of arrays of 16-byte fields
+    float4* od;               // (o.xyz, d.x)
+    float4* dt;               // (d.y, d.z, thr.r, thr.g)
+    float4* tl;               // (thr.b, L.rgb)
+    uint4* ia;                // (path, L.a bits, pixel, sample | bounce << 27)
+    uint4* tv;                // rings M, H: (best t bits, best primitive, next node / leaf of the walk, stack entries)
+    uint4* sk[MPT_OT_PARK / 2u];  // rings M: the walk's stack, two (key, ref) entries per field
+};
+struct OtBudgets {
+    uint32_t trips[MPT_OT_MLEVELS];       // node-loop trips a step of ring M_k may make (the last level: unlimited)
+    uint32_t min_active[MPT_OT_MLEVELS];  // ... and it ends once fewer lanes than this are still walking
+};
 
 struct AccelDev {
     const float4* nodes;    // 7 float4 per node, breadth-first (mpt_accel.h)
     const float4* refleaf;  // 2 float4 per reference leaf: (bmin, 0) (bmax, 0)
-    const float4* always;   // 3 float4 per sphere of the always list: (c, leaf<<1) (r, bits(index), 0, mat) (0,0,0, orig id)
-    uint2* spill;           // [waves][MPT_OT_SPILL][64] stack overflow area
+    const float4* always;   // 5 float4 per sphere of the always list: (c, leaf<<1) (r, bits(index), bits(k), mat) (0,0,0, orig id)
+                            // + the box of its reference leaf (bmin, 0) (bmax, 0)
     uint32_t n_nodes, n_lds_nodes, n_always;
     uint32_t lds_always_off;  // float4 index of the always list in LDS
     uint32_t lds_stack_off;   // byte offset of the stacks in LDS
@@ -57,27 +99,22 @@ struct AccelDev {
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2u* LdsStack;
 
+// Per-lane stack in LDS: entry e of a lane at lds[e * 64] (entry-major: the 64 lanes of a wave hit 64 different bank
+// pairs whatever their depths).  entry = (entry-distance key, child reference).  When the stack is full the FARTHEST
+// of the children being pushed is dropped and the walk is marked incomplete: the caller walks the tree once more from
+// the root with the best t found so far — nearly everything is culled then, so that second pass is short (1.5e-5 of the
+// rays on scene.xml, 0.7 % on bunny x20 with 8 entries).
 struct OtStack {
-    LdsStack lds;     // this lane's column: entry e at lds[e * 64]
-    uint2* spill;     // this lane's column of the wave's spill block: entry e at spill[e * 64]
+    LdsStack lds;
     uint32_t depth;
 };
-__device__ __forceinline__ void ot_push(const OtStack& st, uint32_t& sp, uint32_t key, uint32_t parent, bool& overflow) {
-    if (sp < st.depth) st.lds[sp * 64u] = v2u{key, parent};
-    else if (sp < st.depth + MPT_OT_SPILL) st.spill[(sp - st.depth) * 64u] = make_uint2(key, parent);
-    else {
-        overflow = true;  // deeper than any tree this builder makes: the ray goes to the reference-order walk
-        return;
-    }
-    ++sp;
-}
-__device__ __forceinline__ uint2 ot_pop(const OtStack& st, uint32_t& sp) {
-    --sp;
+__device__ __forceinline__ void ot_push(const OtStack& st, uint32_t& sp, uint32_t key, uint32_t ref, bool& lost) {
     if (sp < st.depth) {
-        const v2u e = st.lds[sp * 64u];
-        return make_uint2(e.x, e.y);
+        st.lds[sp * 64u] = v2u{key, ref};
+        ++sp;
+    } else {
+        lost = true;
     }
-    return st.spill[(sp - st.depth) * 64u];
 }
 
 struct OtRay {
@@ -104,9 +141,10 @@ struct OtNode {
     float4 lx, ly, lz, hx, hy, hz;
     uint4 ref;
 };
+template <bool ALL_LDS>
 __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds, uint32_t n) {
     OtNode nd;
-    if (n < ac.n_lds_nodes) {
+    if (ALL_LDS || n < ac.n_lds_nodes) {
         const LdsNodes q = lds + 7u * n;
         const v4f a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
         nd.lx = make_float4(a.x, a.y, a.z, a.w);
@@ -128,13 +166,6 @@ __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds,
         nd.ref = make_uint4(__float_as_uint(g.x), __float_as_uint(g.y), __float_as_uint(g.z), __float_as_uint(g.w));
     }
     return nd;
-}
-__device__ __forceinline__ uint32_t ot_child_ref(const AccelDev& ac, LdsNodes lds, uint32_t n, uint32_t slot) {
-    if (n < ac.n_lds_nodes) {
-        const __attribute__((address_space(3))) uint32_t* q = (const __attribute__((address_space(3))) uint32_t*)(lds + 7u * n + 6u);
-        return q[slot];
-    }
-    return ((const uint32_t*)(ac.nodes + 7u * (size_t)n + 6u))[slot];
 }
 // entry distance of the ray into one child box as a sort key: float bits with the child slot in the two low bits
 // (t >= 0, so unsigned order = float order; the key rounds the distance DOWN by at most 3 ulp), or KEY_MISS
@@ -212,7 +243,7 @@ template <bool COUNT>
 __device__ __forceinline__ void ot_top_test(const AccelDev& ac, LdsNodes lds, F3 o, F3 d, const OtRay& r, float& T, int& W,
                                             bool& tie, bool& need, WorkCount& wc) {
     for (uint32_t k = 0; k < ac.n_always; ++k) {
-        const LdsNodes q = lds + ac.lds_always_off + 3u * k;
+        const LdsNodes q = lds + ac.lds_always_off + 5u * k;
         const v4f a = q[0], b = q[1], c = q[2];
         Prim3 pr;
         pr.p0 = make_float4(a.x, a.y, a.z, a.w);
@@ -221,7 +252,7 @@ __device__ __forceinline__ void ot_top_test(const AccelDev& ac, LdsNodes lds, F3
         if (COUNT) wc.prim_tests++;
         ot_test_prim(pr, __float_as_uint(b.y), o, d, T, W, tie);
     }
-    const OtNode nd = ot_load_node(ac, lds, 0u);
+    const OtNode nd = ot_load_node<true>(ac, lds, 0u);   // the root is always staged
     const float lim = ot_cull_limit(T, ac.eps_abs);
     const uint32_t k0 = ot_box_key(r, nd.lx.x, nd.ly.x, nd.lz.x, nd.hx.x, nd.hy.x, nd.hz.x, nd.ref.x, lim, 0u);
     const uint32_t k1 = ot_box_key(r, nd.lx.y, nd.ly.y, nd.lz.y, nd.hx.y, nd.hy.y, nd.hz.y, nd.ref.y, lim, 1u);
@@ -236,15 +267,49 @@ __device__ __forceinline__ void ot_top_test(const AccelDev& ac, LdsNodes lds, F3
 
 // Closest-first walk ("while-while": every lane walks nodes until it holds a leaf, then the wave tests leaves together).
 // in/out T, W (best t / primitive so far, e.g. from the top test); tie / overflow are only ever set.
-template <bool COUNT>
-__device__ __forceinline__ void ot_walk(const AccelDev& ac, const SceneDev& sc, LdsNodes lds, const OtStack& st, F3 o, F3 d,
-                                        const OtRay& r, bool active, float& T, int& W, bool& tie, bool& overflow,
-                                        WorkCount& wc) {
-    uint32_t cur = active ? 0u : MPT_OT_DONE;
-    uint32_t sp = 0;
+__device__ __forceinline__ uint32_t ot_pick(const uint4& ref, uint32_t key) {  // two levels of v_cndmask, no branches
+    const bool odd = (key & 1u) != 0u, high = (key & 2u) != 0u;
+    const uint32_t a = odd ? ref.y : ref.x, b = odd ? ref.w : ref.z;
+    return high ? b : a;
+}
+__device__ __forceinline__ uint32_t ot_pop_next(const OtStack& st, uint32_t& sp, float lim) {
+    while (sp > 0u) {
+        --sp;
+        const v2u e = st.lds[sp * 64u];
+        if (__uint_as_float(e.x & ~3u) <= lim) return e.y;
+    }
+    return MPT_OT_DONE;
+}
+// Resumable: (cur, sp) and the lane's stack are the walk's state.  BUDGETED: the step ends when the wave has made
+// `budget` trips of the node loop, or fewer than `min_active` lanes still walk; lanes that are not finished then keep
+// their state (the caller parks them in the next ring, where they meet rays with as long a walk behind them).
+// `overflow` is set when a stack entry had to be dropped: the caller repeats the walk from the root with the T found.
+// Returns true when this lane's walk is complete.
+template <bool COUNT, bool BUDGETED, bool ALL_LDS>
+__device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, LdsNodes lds, const OtStack& st, F3 o, F3 d,
+                                        const OtRay& r, uint32_t& cur, uint32_t& sp, float& T, int& W, bool& tie,
+                                        bool& overflow, uint32_t budget, uint32_t min_active, WorkCount& wc) {
+    uint32_t trips = 0;
+#ifdef MPT_OT_TIMES
+    unsigned long long wt_ = __builtin_amdgcn_s_memtime();
+#define OT_WTOC(field)                                                \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        wc.field += now_ - wt_;                                       \
+        wt_ = now_;                                                   \
+    } while (0)
+#else
+#define OT_WTOC(field) do { } while (0)
+#endif
     for (;;) {
-        while (cur < MPT_OT_LEAF) {
-            const OtNode nd = ot_load_node(ac, lds, cur);
+#ifdef MPT_OT_TIMES
+        wc.ot_rounds++;
+#endif
+        const uint32_t n_entered = (uint32_t)__popcll(__ballot(cur < MPT_OT_LEAF && (!BUDGETED || trips < budget)));
+        while (cur < MPT_OT_LEAF && (!BUDGETED || trips < budget)) {
+            // few lanes still searching, the others hold a leaf: test the leaves now, the search resumes afterwards
+            if ((uint32_t)__popcll(__ballot(true)) * MPT_OT_EARLY < n_entered) break;
+            const OtNode nd = ot_load_node<ALL_LDS>(ac, lds, cur);
             const float lim = ot_cull_limit(T, ac.eps_abs);
             uint32_t k0 = ot_box_key(r, nd.lx.x, nd.ly.x, nd.lz.x, nd.hx.x, nd.hy.x, nd.hz.x, nd.ref.x, lim, 0u);
             uint32_t k1 = ot_box_key(r, nd.lx.y, nd.ly.y, nd.lz.y, nd.hx.y, nd.hy.y, nd.hz.y, nd.ref.y, lim, 1u);
@@ -255,61 +320,98 @@ __device__ __forceinline__ void ot_walk(const AccelDev& ac, const SceneDev& sc, 
                 wc.aabb_hits += (k0 < MPT_OT_KEY_MISS) + (k1 < MPT_OT_KEY_MISS) + (k2 < MPT_OT_KEY_MISS) + (k3 < MPT_OT_KEY_MISS);
                 if (first_active_lane()) wc.node_iters++;
             }
+            if (BUDGETED) trips++;
+#ifdef MPT_OT_TIMES
+            if (first_active_lane()) wc.ot_node_trips++;
+#endif
             ot_sort2(k0, k1);
             ot_sort2(k2, k3);
             ot_sort2(k0, k2);
             ot_sort2(k1, k3);
             ot_sort2(k1, k2);
-            const uint32_t parent = cur;
             if (k0 < MPT_OT_KEY_MISS) {
-                const uint32_t s = k0 & 3u;
-                cur = s == 0u ? nd.ref.x : s == 1u ? nd.ref.y : s == 2u ? nd.ref.z : nd.ref.w;
-                if (k3 < MPT_OT_KEY_MISS) ot_push(st, sp, k3, parent, overflow);
-                if (k2 < MPT_OT_KEY_MISS) ot_push(st, sp, k2, parent, overflow);
-                if (k1 < MPT_OT_KEY_MISS) ot_push(st, sp, k1, parent, overflow);
-            } else {
-                cur = MPT_OT_DONE;
-                while (sp > 0u) {
-                    const uint2 e = ot_pop(st, sp);
-                    if (__uint_as_float(e.x & ~3u) <= lim) {
-                        cur = ot_child_ref(ac, lds, e.y, e.x & 3u);
-                        break;
+                cur = ot_pick(nd.ref, k0);
+                if (k1 < MPT_OT_KEY_MISS) {  // farthest first, so that the nearest is popped first
+                    if (k2 < MPT_OT_KEY_MISS) {
+                        if (k3 < MPT_OT_KEY_MISS) ot_push(st, sp, k3, ot_pick(nd.ref, k3), overflow);
+                        ot_push(st, sp, k2, ot_pick(nd.ref, k2), overflow);
                     }
+                    ot_push(st, sp, k1, ot_pick(nd.ref, k1), overflow);
                 }
+            } else {
+                cur = ot_pop_next(st, sp, lim);
             }
         }
-        if (__ballot(cur != MPT_OT_DONE) == 0ull) break;
-        if (cur != MPT_OT_DONE) {  // a leaf: primitives [first, first + count) in index order
+        if (BUDGETED) trips = wave_max_u32(trips);  // a lane that left the loop early adopts the trips the others made
+        OT_WTOC(ot_node_cycles);
+        if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF) {  // a leaf: primitives [first, first + count) in index order
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
             if (COUNT && first_active_lane()) wc.outer_iters++;
+#ifdef MPT_OT_PREFETCH   // loading primitive k + 1 while k is tested: measured slower (12 more VGPRs live: 28.7 vs 28.1 ms)
+            Prim3 nxt = load_prim(sc, lds, first);
+#endif
             for (uint32_t k = 0; k < count; ++k) {
+#ifdef MPT_OT_PREFETCH
+                const Prim3 pr = nxt;
+                if (k + 1u < count) nxt = load_prim(sc, lds, first + k + 1u);
+#else
                 const Prim3 pr = load_prim(sc, lds, first + k);
+#endif
                 if (COUNT) {
                     if (first_active_lane()) wc.prim_iters++;
                 }
+#ifdef MPT_OT_TIMES
+                if (first_active_lane()) wc.ot_leaf_trips++;
+#endif
                 if (ac.n_always != 0u && prim_type(pr.p0) == 0) continue;  // spheres are on the always list
                 if (COUNT) wc.prim_tests++;
                 ot_test_prim(pr, first + k, o, d, T, W, tie);
             }
-            const float lim = ot_cull_limit(T, ac.eps_abs);
-            cur = MPT_OT_DONE;
-            while (sp > 0u) {
-                const uint2 e = ot_pop(st, sp);
-                if (__uint_as_float(e.x & ~3u) <= lim) {
-                    cur = ot_child_ref(ac, lds, e.y, e.x & 3u);
-                    break;
-                }
-            }
+            cur = ot_pop_next(st, sp, ot_cull_limit(T, ac.eps_abs));
         }
+        OT_WTOC(ot_leaf_cycles);
+        const unsigned long long going = __ballot(cur != MPT_OT_DONE && (!BUDGETED || trips < budget));
+        if (going == 0ull) break;
+        if (BUDGETED && (uint32_t)__popcll(going) < min_active) break;
     }
+    return cur == MPT_OT_DONE;
 }
 
 // Final check: the reference's slab test (PathTracing.h:52-72, exact arithmetic, best t = +inf) on the winner's
-// REFERENCE leaf box must pass, and the winner's t must not lie in front of that box.
-__device__ __forceinline__ bool ot_final_check(const AccelDev& ac, const SceneDev& sc, LdsNodes lds, F3 o, F3 d, float T, int W) {
+// REFERENCE leaf box must pass, and the winner's t must not lie in front of that box.  The box is first tested with the
+// walk's reciprocal arithmetic and an error bound ((|t| + |o/d|) * 2^-20 covers v_rcp_f32's 1 ulp, the rounding of o/d
+// and of the fma, with a factor 2 to spare): when the answer is certain, the three IEEE divisions of the exact test are
+// skipped — they are needed only for winners within that bound of their box (hits on the ground sphere next to the origin).
+__device__ __forceinline__ bool ot_final_check(const AccelDev& ac, const SceneDev& sc, LdsNodes lds, F3 o, F3 d, const OtRay& r,
+                                               float T, int W) {
     const Prim3 pr = load_prim(sc, lds, (uint32_t)W);
-    const uint32_t leaf = prim_ref_leaf(pr.p0);
-    const float4 n0 = ac.refleaf[2u * (size_t)leaf], n1 = ac.refleaf[2u * (size_t)leaf + 1u];
+    float4 n0, n1;
+    if (ac.n_always != 0u && prim_type(pr.p0) == 0) {  // a sphere of the always list: its leaf box is in LDS
+        const LdsNodes q = lds + ac.lds_always_off + 5u * (uint32_t)__float_as_int(pr.p1.z) + 3u;
+        const v4f a = q[0], b = q[1];
+        n0 = make_float4(a.x, a.y, a.z, 0.0f);
+        n1 = make_float4(b.x, b.y, b.z, 0.0f);
+    } else {
+        const uint32_t leaf = prim_ref_leaf(pr.p0);
+        n0 = ac.refleaf[2u * (size_t)leaf];
+        n1 = ac.refleaf[2u * (size_t)leaf + 1u];
+    }
+    {
+        float t0 = fmaf(n0.x, r.idx, -r.ox), t1 = fmaf(n1.x, r.idx, -r.ox);
+        float lo = fminf(t0, t1), hi = fmaxf(t0, t1), m = fmaxf(fabsf(t0), fabsf(t1));
+        t0 = fmaf(n0.y, r.idy, -r.oy);
+        t1 = fmaf(n1.y, r.idy, -r.oy);
+        lo = fmaxf(lo, fminf(t0, t1));
+        hi = fminf(hi, fmaxf(t0, t1));
+        m = fmaxf(m, fmaxf(fabsf(t0), fabsf(t1)));
+        t0 = fmaf(n0.z, r.idz, -r.oz);
+        t1 = fmaf(n1.z, r.idz, -r.oz);
+        lo = fmaxf(fmaxf(lo, fminf(t0, t1)), 0.0001f);
+        hi = fminf(hi, fmaxf(t0, t1));
+        m = fmaxf(m, fmaxf(fabsf(t0), fabsf(t1)));
+        const float err = (m + fmaxf(fabsf(r.ox), fmaxf(fabsf(r.oy), fabsf(r.oz)))) * 9.5367431640625e-07f;
+        if (hi - err > lo + err && T >= lo + err) return true;  // (a NaN anywhere fails this and takes the exact test)
+    }
     const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;
     float t0 = (n0.x - o.x) * idx, t1 = (n1.x - o.x) * idx;
     float lo = fmaxf(0.0001f, idx < 0.0f ? t1 : t0);
@@ -338,10 +440,18 @@ __device__ __forceinline__ void closest_hit_ordered(const AccelDev& ac, const Sc
     if (degenerate) flags |= 1u;
     const OtRay r = ot_ray(o, d);
     if (valid && !degenerate) ot_top_test<COUNT>(ac, lds, o, d, r, T, W, tie, need, wc);
-    ot_walk<COUNT>(ac, sc, lds, st, o, d, r, valid && need && !degenerate, T, W, tie, overflow, wc);
+    uint32_t cur = valid && need && !degenerate ? 0u : MPT_OT_DONE, sp = 0;
+    ot_walk<COUNT, false, false>(ac, sc, lds, st, o, d, r, cur, sp, T, W, tie, overflow, 0xFFFFFFFFu, 0u, wc);
+    for (int pass = 0; pass < 4 && __ballot(overflow) != 0ull; ++pass) {  // entries were dropped: again, with the T found
+        cur = overflow ? 0u : MPT_OT_DONE;
+        sp = 0;
+        bool again = false;
+        ot_walk<COUNT, false, false>(ac, sc, lds, st, o, d, r, cur, sp, T, W, tie, again, 0xFFFFFFFFu, 0u, wc);
+        overflow = again;
+    }
     if (tie) flags |= 2u;
     if (overflow) flags |= 8u;
-    if (valid && flags == 0u && W >= 0 && !ot_final_check(ac, sc, lds, o, d, T, W)) flags |= 4u;
+    if (valid && flags == 0u && W >= 0 && !ot_final_check(ac, sc, lds, o, d, r, T, W)) flags |= 4u;
     if (valid && flags != 0u) {
         uint32_t node = 0;
         T = INFINITY;
@@ -353,7 +463,7 @@ __device__ __forceinline__ void closest_hit_ordered(const AccelDev& ac, const Sc
 __device__ __forceinline__ void ot_stage(const SceneDev& sc, const AccelDev& ac, float4* lds) {
     const uint32_t n4 = ac.n_lds_nodes * 7u, p4 = sc.n_lds_prims * 3u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = ac.nodes[i];
-    for (uint32_t i = threadIdx.x; i < ac.n_always * 3u; i += blockDim.x) lds[ac.lds_always_off + i] = ac.always[i];
+    for (uint32_t i = threadIdx.x; i < ac.n_always * 5u; i += blockDim.x) lds[ac.lds_always_off + i] = ac.always[i];
     for (uint32_t i = threadIdx.x; i < p4; i += blockDim.x) lds[sc.lds_prim_off + i] = sc.prims[i];
     for (uint32_t i = threadIdx.x; i < sc.n_lds_mats * 2u; i += blockDim.x) lds[sc.lds_mat_off + i] = sc.mats[i];
     __syncthreads();
@@ -362,16 +472,21 @@ __device__ __forceinline__ OtStack ot_stack(const AccelDev& ac, float4* lds_raw,
     OtStack st;
     const uint32_t lane = threadIdx.x & 63u, wave_local = threadIdx.x >> 6;
     st.lds = (LdsStack)(lds_raw + (ac.lds_stack_off >> 4)) + wave_local * ac.stack_depth * 64u + lane;
-    st.spill = ac.spill + (size_t)wave_global * MPT_OT_SPILL * 64u + lane;
     st.depth = ac.stack_depth;
+    (void)wave_global;
     return st;
 }
 
 // ---- the pipeline kernel ------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassParams pp, AccelDev ac, WaveRings ring,
-                                                                          uint32_t wl_block, uint32_t wl_min, uint32_t wl_div,
-                                                                          uint32_t walk_now_min) {
+#define MPT_OT_RING_R 0u
+#define MPT_OT_RING_H 1u
+#define MPT_OT_RING_E 2u
+#define MPT_OT_RING_M 3u       // M0 ... M(MLEVELS-1)
+#define MPT_OT_NONE 0xFFu
+
+template <bool COUNT, bool ALL_LDS>
+__global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassParams pp, AccelDev ac, OtRings ring, OtBudgets budgets,
+                                                                          uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_raw[];
     ot_stage(pp.scene, ac, lds_raw);
     const LdsNodes lds = (LdsNodes)lds_raw;
@@ -381,23 +496,32 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const OtStack st = ot_stack(ac, lds_raw, wave_id);
     const uint32_t wbase = wave_id * (MPT_OT_RINGS * MPT_WL_RING);
-    uint32_t cntR = 0, cntM = 0, cntE = 0;           // wave-uniform ring fills (the rings are stacks: newest first)
+    uint32_t cnt[MPT_OT_RINGS];   // wave-uniform ring fills (the rings are stacks: newest first)
+#pragma unroll
+    for (uint32_t k = 0; k < MPT_OT_RINGS; ++k) cnt[k] = 0u;
     uint32_t cur = 0, end = 0;
     const uint32_t n_tiles = total_paths / (pp.S * 64u);
     const uint32_t waves_per_group = (n_waves + MPT_NGROUP - 1u) / MPT_NGROUP;
     uint32_t grp = blockIdx.x & (MPT_NGROUP - 1u);
     uint32_t seen = 0;
     bool exhausted = false;
+    uint32_t tile_cached = 0xFFFFFFFFu, tile_xy_cached = 0u;
     uint32_t n_rays = 0, n_paths = 0, n_flagged = 0, n_parked = 0;
     WorkCount wc = {};
+#ifdef MPT_OT_TIMES
+    unsigned long long ot_acc[OT_NREG] = {}, ot_steps[MPT_OT_RINGS + 1] = {}, ot_lanes[MPT_OT_RINGS + 1] = {};
+#endif
     for (;;) {
-        // ---- step choice ------------------------------------------------------------------------------------------
-        uint32_t takeR = 0, takeM = 0, takeE = 0;
-        bool primary = false, walk_all = false;
-        if (cntE >= 64u) takeE = 64u;
-        else if (cntM >= 64u) takeM = 64u;
-        else if (cntR >= 64u) takeR = 64u;
-        else {
+        OT_TIC();
+        // ---- step choice: a full wave of the most advanced kind of work; else new paths; else what is left ----------------
+        uint32_t kind = MPT_OT_NONE;  // ring to pop from; NONE = primary step
+        if (cnt[MPT_OT_RING_E] >= 64u) kind = MPT_OT_RING_E;
+        else if (cnt[MPT_OT_RING_H] >= 64u) kind = MPT_OT_RING_H;
+#pragma unroll
+        for (int k = (int)MPT_OT_RINGS - 1; k >= (int)MPT_OT_RING_M; --k)  // the longest walks first
+            if (kind == MPT_OT_NONE && cnt[k] >= 64u) kind = (uint32_t)k;
+        if (kind == MPT_OT_NONE && cnt[MPT_OT_RING_R] >= 64u) kind = MPT_OT_RING_R;
+        if (kind == MPT_OT_NONE) {
             if (!exhausted && cur == end) {  // guided self-scheduling of path ids, as k_wavelocal (mpt_kernels.h)
                 uint32_t k = 0, blk = 0, rend = 0;
                 bool got = false;
@@ -431,130 +555,252 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                     end = (k + blk < rend) ? k + blk : rend;
                 }
             }
-            if (!exhausted) {
-                primary = true;
-            } else if (cntM + cntR != 0u) {  // drain: tree rays first, topped up with fresh rays; everything walks now
-                takeM = cntM;
-                takeR = cntR < 64u - takeM ? cntR : 64u - takeM;
-                walk_all = true;
-            } else if (cntE != 0u) {
-                takeE = cntE;
-            } else {
-                break;
+            if (exhausted) {  // drain: partial steps, tree walks and hits first (they feed ring R)
+#pragma unroll
+                for (int k = (int)MPT_OT_RINGS - 1; k >= (int)MPT_OT_RING_M; --k)
+                    if (kind == MPT_OT_NONE && cnt[k] != 0u) kind = (uint32_t)k;
+                if (kind == MPT_OT_NONE) {
+                    if (cnt[MPT_OT_RING_H] != 0u) kind = MPT_OT_RING_H;
+                    else if (cnt[MPT_OT_RING_R] != 0u) kind = MPT_OT_RING_R;
+                    else if (cnt[MPT_OT_RING_E] != 0u) kind = MPT_OT_RING_E;
+                    else break;
+                }
             }
         }
+        OT_TOC(0);
         // ---- rays of the step ---------------------------------------------------------------------------------------
         PathState ps;
         PathRngDev g;
-        bool valid = false, from_m = false;
+        bool valid = false;
         float T = INFINITY;
         int W = -1;
-        if (primary) {
-            ps.path = range_chunk_to_path_chunk(pp, cur >> 6, grp) * 64u + lane;
+        uint32_t at = 0, walk_cur = 0u, walk_sp = 0u;   // walk state of a ring-M ray (fresh: the root, empty stack)
+        bool walk_lost = false, walk_again = false;     // a stack entry was dropped / this is already the second walk
+        if (kind == MPT_OT_NONE) {
+            // 64 new paths = one 8x8 pixel tile at one sample index.  Everything about the tile is wave-uniform; its table
+            // entry is kept from the previous primary step (consecutive steps of a claim walk the samples of one tile)
+            const uint32_t pchunk = range_chunk_to_path_chunk(pp, cur >> 6, grp);  // = tile * S + sample
             cur += 64u;
-            uint32_t px, py, sidx;
-            if (path_to_pixel(pp, ps.path, px, py, sidx)) {
+            uint32_t tl, sidx;
+            if (pp.s_shift != 0xFFu) {
+                tl = pchunk >> pp.s_shift;
+                sidx = pchunk & (pp.S - 1u);
+            } else {
+                tl = pchunk / pp.S;
+                sidx = pchunk - tl * pp.S;
+            }
+            if (tl != tile_cached) {
+                tile_cached = tl;
+                tile_xy_cached = (uint32_t)__builtin_amdgcn_readfirstlane((int)pp.tile_xy[tl]);
+            }
+            ps.path = pchunk * 64u + lane;
+            const uint32_t px = (tile_xy_cached & 0xFFFFu) * 8u + (lane & 7u), py = (tile_xy_cached >> 16) * 8u + (lane >> 3);
+            if (px < pp.width && py < pp.height) {
                 gen_primary(pp, px, py, pp.sample_begin + sidx, ps, g);
                 valid = true;
                 n_paths++;
             }
         } else {
-            uint32_t at = 0;
-            if (lane < takeM) {
-                at = wbase + MPT_WL_RING + (cntM - takeM + lane);
-                from_m = true;
-                valid = true;
-            } else if (lane < takeM + takeR) {
-                at = wbase + (cntR - takeR + (lane - takeM));
-                valid = true;
-            } else if (lane < takeE) {
-                at = wbase + 2u * MPT_WL_RING + (cntE - takeE + lane);
-                valid = true;
-            }
-            cntM -= takeM;
-            cntR -= takeR;
-            cntE -= takeE;
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < MPT_OT_RINGS; ++k)
+                if (k == kind) c = cnt[k];
+            const uint32_t take = c < 64u ? c : 64u;
+            valid = lane < take;
+            at = wbase + kind * MPT_WL_RING + (c - take + lane);
+#pragma unroll
+            for (uint32_t k = 0; k < MPT_OT_RINGS; ++k)
+                if (k == kind) cnt[k] = c - take;
             if (valid) {
-                const float4 a = ring.od[at], b = ring.dt[at], cc = ring.tl[at];
-                const uint4 ia = ring.ia[at];
+                const float4 a = ring.od[at], b = ring.dt[at];
                 ps.o = f3(a.x, a.y, a.z);
                 ps.d = f3(a.w, b.x, b.y);
-                ps.thr = f3(b.z, b.w, cc.x);
-                ps.L = f3(cc.y, cc.z, cc.w);
-                ps.La = __uint_as_float(ia.y);
-                ps.path = ia.x;
-                ps.bounce = ia.w >> 27;
-                g.pixel = ia.z;
-                g.sample = ia.w & 0x07FFFFFFu;
-                g.lit_seed = 0;
-                if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
-                if (from_m) {
+                ps.thr.x = b.z;
+                ps.thr.y = b.w;
+                if (kind != MPT_OT_RING_R && kind != MPT_OT_RING_E) {
                     const uint4 tv = ring.tv[at];
                     T = __uint_as_float(tv.x);
                     W = (int)tv.y;
+                    walk_cur = tv.z;
+                    walk_sp = tv.w & 0xFFFFu;
+                    walk_lost = (tv.w & 0x40000000u) != 0u;
+                    walk_again = (tv.w & 0x80000000u) != 0u;
+                }
+            }
+            if (kind >= MPT_OT_RING_M) {  // a parked walk brings its stack along: back into this lane's LDS column
+                if (!valid) walk_cur = MPT_OT_DONE;
+                const uint32_t deepest = wave_max_u32(valid ? walk_sp : 0u);
+#pragma unroll
+                for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
+                    if (2u * k >= deepest) break;
+                    if (valid && walk_sp > 2u * k) {
+                        const uint4 e = ring.sk[k][at];
+                        st.lds[(2u * k) * 64u] = v2u{e.x, e.y};
+                        st.lds[(2u * k + 1u) * 64u] = v2u{e.z, e.w};
+                    }
                 }
             }
         }
-        bool flagged = false, parked = false, finished = false;
-        if (takeE != 0u) {
+        // the rest of a record is not needed by the tree walk: ring M steps load it afterwards
+        auto load_rest = [&]() {
+            const float4 cc = ring.tl[at];
+            const uint4 ia = ring.ia[at];
+            ps.thr.z = cc.x;
+            ps.L = f3(cc.y, cc.z, cc.w);
+            ps.La = __uint_as_float(ia.y);
+            ps.path = ia.x;
+            ps.bounce = ia.w >> 27;
+            g.pixel = ia.z;
+            g.sample = ia.w & 0x07FFFFFFu;
+            g.lit_seed = 0;
+            if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+        };
+        if (valid && kind != MPT_OT_NONE && kind < MPT_OT_RING_M) load_rest();
+        OT_TOC(1);
+#ifdef MPT_OT_TIMES
+        ot_steps[kind == MPT_OT_NONE ? MPT_OT_RINGS : kind] += 1;
+        ot_lanes[kind == MPT_OT_NONE ? MPT_OT_RINGS : kind] += (unsigned long long)__popcll(__ballot(valid));
+#endif
+        uint32_t dest = MPT_OT_NONE;      // ring this lane's ray goes to next
+        bool shade = false;               // ... or its closest hit is final: one bounce of shading now
+        const OtRay r = ot_ray(ps.o, ps.d);
+        if (kind == MPT_OT_NONE || kind == MPT_OT_RING_R) {
+            // ---- TOP TEST: always-list spheres + the root's boxes ------------------------------------------------------
+            if (valid) {
+                bool tie = false, need = false;
+                if (ot_degenerate(ps.o, ps.d, ac.o_limit)) {
+                    dest = MPT_OT_RING_E;
+                } else {
+                    ot_top_test<COUNT>(ac, lds, ps.o, ps.d, r, T, W, tie, need, wc);
+                    if (tie) dest = MPT_OT_RING_E;
+                    else if (need) dest = MPT_OT_RING_M;
+#ifndef MPT_OT_TOP_HITS_TO_RING_H
+                    // a sphere of the always list and nothing to walk: checked and shaded here (sending these hits through
+                    // ring H as well cost more in ring traffic than the divergence it removes: 28.7 -> 28.1 ms)
+                    else if (W >= 0 && !ot_final_check(ac, pp.scene, lds, ps.o, ps.d, r, T, W)) dest = MPT_OT_RING_E;
+                    else shade = true;  // ... or nothing hit at all: the sky
+#else
+                    else if (W >= 0) dest = MPT_OT_RING_H;
+                    else shade = true;
+#endif
+                }
+            }
+            OT_TOC(2);
+        } else if (kind >= MPT_OT_RING_M) {
+            // ---- closest-first walk, continued for this ring's budget of node-loop trips ------------------------------
+            bool tie = false, done;
+            uint32_t budget = 0u, min_active = 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < MPT_OT_MLEVELS; ++k)
+                if (kind == MPT_OT_RING_M + k) {
+                    budget = budgets.trips[k];
+                    min_active = budgets.min_active[k];
+                }
+            if (kind + 1u < MPT_OT_RINGS || min_active != 0u)
+                done = ot_walk<COUNT, true, ALL_LDS>(ac, pp.scene, lds, st, ps.o, ps.d, r, walk_cur, walk_sp, T, W, tie, walk_lost,
+                                                     kind + 1u < MPT_OT_RINGS ? budget : 0x7FFFFFFFu, min_active, wc);
+            else
+                done = ot_walk<COUNT, false, ALL_LDS>(ac, pp.scene, lds, st, ps.o, ps.d, r, walk_cur, walk_sp, T, W, tie, walk_lost,
+                                                      0xFFFFFFFFu, 0u, wc);
+            if (valid) {
+                load_rest();
+                if (tie) dest = MPT_OT_RING_E;   // (whatever is left of the walk does not matter then)
+                else if (!done) dest = kind + 1u < MPT_OT_RINGS ? kind + 1u : kind;  // parked with its walk state
+                else if (walk_lost) {  // the stack dropped entries: once more from the root, now with the T found
+                    if (walk_again) dest = MPT_OT_RING_E;
+                    else {
+                        dest = MPT_OT_RING_M;
+                        walk_cur = 0u;
+                        walk_sp = 0u;
+                        walk_lost = false;
+                        walk_again = true;
+                    }
+                }
+                else if (W >= 0) dest = MPT_OT_RING_H;
+                else shade = true;
+            }
+            OT_TOC(3);
+        } else if (kind == MPT_OT_RING_H) {
+            // ---- hits: the final check decides between shading and the reference-order walk ---------------------------
+            if (valid) {
+                if (ot_final_check(ac, pp.scene, lds, ps.o, ps.d, r, T, W)) shade = true;
+                else dest = MPT_OT_RING_E;
+            }
+            OT_TOC(4);
+        } else {
             // ---- reference-order walk (PathTracing.h:75-204 as closest_hit_resume restates it) ----------------------
             if (valid) {
                 uint32_t node = 0;
                 T = INFINITY;
                 W = -1;
                 closest_hit_resume<COUNT, false, false>(pp.scene, lds, ps.o, ps.d, node, T, W, 0xFFFFFFFFu, wc);
-                finished = true;
+                shade = true;
             }
-        } else {
-            bool tie = false, overflow = false, need = from_m;
-            const OtRay r = ot_ray(ps.o, ps.d);
-            if (valid && !from_m) {
-                if (ot_degenerate(ps.o, ps.d, ac.o_limit)) flagged = true;
-                else ot_top_test<COUNT>(ac, lds, ps.o, ps.d, r, T, W, tie, need, wc);
-            }
-            const bool wants = valid && need && !flagged;
-            const bool walk_now = walk_all || takeM != 0u || (uint32_t)__popcll(__ballot(wants)) >= walk_now_min;
-            if (walk_now) {
-                ot_walk<COUNT>(ac, pp.scene, lds, st, ps.o, ps.d, r, wants, T, W, tie, overflow, wc);
-            } else {
-                parked = wants;
-            }
-            if (valid && !parked && !flagged) {
-                flagged = tie || overflow;
-                if (!flagged && W >= 0) flagged = !ot_final_check(ac, pp.scene, lds, ps.o, ps.d, T, W);
-                finished = !flagged;
-            }
+            OT_TOC(5);
         }
-        // ---- shading of the rays whose closest hit is known ---------------------------------------------------------
-        bool alive = false;
-        if (finished) {
+        // ---- one bounce of shading for the rays whose closest hit is final ----------------------------------------------
+        if (shade) {
             n_rays++;
-            alive = shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W);
-            if (!alive) store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+            if (shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W)) dest = MPT_OT_RING_R;
+            else store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
         }
-        n_flagged += flagged ? 1u : 0u;
-        n_parked += parked ? 1u : 0u;
-        // ---- wave64 compaction into the rings: ballot + mbcnt prefix, ring fills stay wave-uniform -------------------
-        const unsigned long long am = __ballot(alive), pm = __ballot(parked), fm = __ballot(flagged);
-        if ((am | pm | fm) != 0ull) {
-            uint32_t at = 0;
-            if (alive) at = wbase + cntR + wave_rank(am);
-            if (parked) at = wbase + MPT_WL_RING + cntM + wave_rank(pm);
-            if (flagged) at = wbase + 2u * MPT_WL_RING + cntE + wave_rank(fm);
-            if (alive || parked || flagged) {
-                ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-                ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
-                if (parked) ring.tv[at] = make_uint4(__float_as_uint(T), (uint32_t)W, 0u, 0u);
+        n_flagged += dest == MPT_OT_RING_E ? 1u : 0u;
+        n_parked += dest != MPT_OT_NONE && dest >= MPT_OT_RING_M ? 1u : 0u;
+        OT_TOC(6);
+        // ---- wave64 compaction into the rings: ballot + mbcnt prefix per ring, fills stay wave-uniform ------------------
+        if (__ballot(dest != MPT_OT_NONE) != 0ull) {
+            uint32_t to = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < MPT_OT_RINGS; ++k) {
+                const unsigned long long m = __ballot(dest == k);
+                if (dest == k) to = wbase + k * MPT_WL_RING + cnt[k] + wave_rank(m);
+                cnt[k] += (uint32_t)__popcll(m);
             }
-            cntR += (uint32_t)__popcll(am);
-            cntM += (uint32_t)__popcll(pm);
-            cntE += (uint32_t)__popcll(fm);
+            if (dest != MPT_OT_NONE) {
+                ring.od[to] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+                ring.dt[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+                ring.tl[to] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+                ring.ia[to] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+                if (dest == MPT_OT_RING_H || dest >= MPT_OT_RING_M) {
+                    // a ray parked by a top test starts its walk at the root (walk_cur = 0, walk_sp = 0 there)
+                    ring.tv[to] = make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,
+                                             walk_sp | (walk_lost ? 0x40000000u : 0u) | (walk_again ? 0x80000000u : 0u));
+                    if (kind >= MPT_OT_RING_M && dest >= MPT_OT_RING_M) {
+#pragma unroll
+                        for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
+                            if (walk_sp > 2u * k) {
+                                const v2u e0 = st.lds[(2u * k) * 64u], e1 = st.lds[(2u * k + 1u) * 64u];
+                                ring.sk[k][to] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+                            }
+                        }
+                    }
+                }
+            }
         }
-        const uint32_t worst = cntR > cntM ? (cntR > cntE ? cntR : cntE) : (cntM > cntE ? cntM : cntE);
-        if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen: a step never adds more rays than it took + 64
+        uint32_t worst = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < MPT_OT_RINGS; ++k) worst = cnt[k] > worst ? cnt[k] : worst;
+        if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen: only a primary step adds rays (<= 64), and it
+                                                          // runs only while every ring holds < 64: at most RINGS * 63 + 64
+        OT_TOC(7);
     }
+#ifdef MPT_OT_TIMES
+    {
+        unsigned long long v[5] = {wc.ot_node_cycles, wc.ot_leaf_cycles, wc.ot_node_trips, wc.ot_leaf_trips, wc.ot_rounds};
+        for (int k = 0; k < 5; ++k) {
+            if (k < 2 || k == 4) v[k] = __shfl(v[k], 0);   // cycles / rounds are per wave: lane 0's copy
+            else for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+            if (lane == 0) atomicAdd(&g_ot_walk[k], v[k]);
+        }
+    }
+    if (lane == 0) {
+        for (int k = 0; k < OT_NREG; ++k) atomicAdd(&g_ot_times[k], ot_acc[k]);
+        for (int k = 0; k <= (int)MPT_OT_RINGS; ++k) {
+            atomicAdd(&g_ot_times[OT_NREG + k], ot_steps[k]);
+            atomicAdd(&g_ot_times[OT_NREG + 8 + k], ot_lanes[k]);
+        }
+    }
+#endif
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
     {
         unsigned long long a = n_flagged, b = n_parked;

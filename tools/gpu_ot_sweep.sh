@@ -3,6 +3,6 @@
 export SPP=${SPP:-256} PIPE=3 REPS=3
 for SCENE in scene.xml bunny20.xml; do
   export SCENE
-  for W in 1 8 16 24 32 48 65; do echo -n "$SCENE walk_now $W: "; MPT_OT_WALK_NOW=$W python3 tools/prof_run.py | tail -1; done
-  for S in 4 6 8 10; do echo -n "$SCENE stack $S: "; MPT_OT_STACK=$S python3 tools/prof_run.py | tail -1; done
+  for B in "2,6" "4,10" "6,16" "8,20" "12,32" "4,1000000" "1000000,1000000"; do echo -n "$SCENE budgets $B: "; MPT_OT_BUDGETS=$B python3 tools/prof_run.py | tail -1; done
+  for A in "0,0,0" "0,16,16" "0,32,32" "16,24,24"; do echo -n "$SCENE min_active $A: "; MPT_OT_MIN_ACTIVE=$A python3 tools/prof_run.py | tail -1; done
 done

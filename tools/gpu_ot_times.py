@@ -1,0 +1,35 @@
+"""Where the time of k_ordered goes (diagnostics build, -DMPT_OT_TIMES): cycles per region summed over all waves, steps and
+lanes per step kind.   usage: MPT_LIB=<libmpt_hip_times.so> python tools/gpu_ot_times.py [scene.xml] [spp]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metalpathtracer_amd import capi, host
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+name = sys.argv[1] if len(sys.argv) > 1 else "scene.xml"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", name), sc); assert st == 0
+sc.buildBVH(int(os.environ.get("BVH", "0")))
+ctx = capi.Context(0); ctx.upload_scene(*sc.buffers())
+W, H = 1920, 1080
+ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
+L = capi.load()
+buf = (C.c_ulonglong * 32)()
+for rep in range(2):
+    L.mpt_debug_ot_times(buf, 1)
+    ctx.clear_sum(); ctx.reset_stats()
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=spp, pipeline=capi.PIPE_ORDERED)
+    s = ctx.stats()
+    L.mpt_debug_ot_times(buf, 0)
+v = list(buf)
+tot = sum(v[:8])
+names = ["select/claim", "fetch (gen / ring load)", "top test", "walk", "final check", "exact walk", "shade", "push"]
+print("%s %d spp: %.2f ms, %d rays, retraced %d, parked %d" % (name, spp, s["total_ms"], s["rays"], s["exact_retraces"], s["tree_parked"]))
+for n, c in zip(names, v[:8]):
+    print("  %-26s %5.1f %%" % (n, 100.0 * c / tot))
+kinds = ["ring R (fresh rays)", "ring H (hits)", "ring E (reference order)", "ring M0 (tree walk)", "ring M1", "ring M2", "primary"]
+for k in range(7):
+    if v[8 + k]:
+        print("  steps %-26s %10d  lanes/step %.1f" % (kinds[k], v[8 + k], v[16 + k] / v[8 + k]))
+w = v[24:29]
+if w[2]:
+    print("  walk: node loop %.1f %% of the walk cycles, %.0f cycles per wave trip (%d trips); leaf loop %.0f cycles per wave trip (%d trips); %d rounds"
+          % (100.0 * w[0] / max(1, w[0] + w[1]), w[0] / w[2], w[2], w[1] / max(1, w[3]), w[3], w[4]))

@@ -16,5 +16,5 @@ for line in out.splitlines():
     elif cur and ":" in t:
         k, v = t.split(":", 1); rows[cur][k.strip()] = v.strip()
 for k, v in rows.items():
-    if not any(x in k for x in ("k_step", "k_mega", "k_regen", "k_wavelocal", "k_stream", "k_trace")): continue
+    if not any(x in k for x in ("k_step", "k_mega", "k_regen", "k_wavelocal", "k_stream", "k_trace", "k_ordered")): continue
     print("%-48s VGPR %3s SGPR %3s scratch %4s occ %s spillS %s spillV %s" % (k[:48], v.get("VGPRs"), v.get("TotalSGPRs"), v.get("ScratchSize [bytes/lane]"), v.get("Occupancy [waves/SIMD]"), v.get("SGPRs Spill"), v.get("VGPRs Spill")))
