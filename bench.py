@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "scene.xml"))
     ap.add_argument("--pipeline", default=os.environ.get("MPT_BENCH_PIPELINE", "default"),
                     choices=["default", "wavefront", "megakernel", "wavelocal", "ordered"])
+    ap.add_argument("--bvh", default="reference", choices=["reference", "binned", "gpu"],
+                    help="tree builder: the reference's sweep SAH (default: the drop-in behaviour), the host binned SAH, the GPU LBVH")
     ap.add_argument("--slots", type=int, default=0, help="wavefront width (ray slots per iteration), 0 = default")
     ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +159,7 @@ def main():
     st, log = host.SceneLoader.LoadSceneFromXML(args.scene, sc)
     if st != 0:
         sys.exit("cannot load %s: %s" % (args.scene, log))
-    sc.buildBVH()
+    sc.buildBVH({"reference": host.BVH_REFERENCE_SWEEP, "binned": host.BVH_BINNED_CENTROID, "gpu": host.BVH_GPU_LBVH}[args.bvh])
     buffers = sc.buffers()
     P, T = sc.getPrimitiveCount(), sc.getTriangleCount()
     ctx = capi.Context(local)
@@ -169,6 +171,8 @@ def main():
     ctx.set_sum_buffer(fb.data_ptr())
     pipe = {"default": capi.DEFAULT_PIPELINE, "wavefront": capi.PIPE_WAVEFRONT, "megakernel": capi.PIPE_MEGAKERNEL,
             "wavelocal": capi.PIPE_WAVELOCAL, "ordered": capi.PIPE_ORDERED}[args.pipeline]
+    if pipe == capi.PIPE_AUTO:   # what mpt_render resolves AUTO to (include/mpt.h), so that the line names the kernel that ran
+        pipe = capi.PIPE_ORDERED if P >= 16384 and ctx.accel_info()["ordered_ok"] else capi.PIPE_WAVELOCAL
     kw = dict(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_LAMBERT, max_depth=args.depth, pipeline=pipe, seed=(1, 0),
               shard_rank=rank, shard_count=world, slots_per_iter=args.slots)
 
@@ -244,7 +248,7 @@ def main():
             "config": {
                 "workload": "scene.xml %dx%d x %d spp per step, depth %d (%d steps timed)" % (W, H, spp, args.depth,
                                                                                            args.steps),
-                "prims": P, "bvh_nodes": sc.getBVHNodeCount(), "rng": "philox4x32-10 (pixel,sample,bounce)",
+                "prims": P, "bvh_nodes": sc.getBVHNodeCount(), "bvh_builder": args.bvh, "rng": "philox4x32-10 (pixel,sample,bounce)",
                 "pipeline": PIPE_NAMES[pipe],
                 "parallelism": "8x8-tile interleave over %d rank(s)%s" % (world, " + 1 RCCL reduce(sum) of the HDR framebuffer" if world > 1 else ""),
                 "paths": paths_total, "rays": rays_total, "rays_per_path": rays_total / max(1, paths_total),

@@ -60,10 +60,14 @@ enum { MPT_PIPE_WAVEFRONT = 0,  /* global SoA ray queues + wave64 ballot compact
        MPT_PIPE_MEGAKERNEL = 1, /* one thread per path, whole bounce loop in registers                */
        MPT_PIPE_WAVELOCAL = 2,  /* persistent waves, wave-private ray rings + ballot compaction; pipelines 0-2 walk
                                    the BVH in the reference's own order (PathTracing.h:188-193)                      */
-       MPT_PIPE_ORDERED = 3 };  /* the same wave-local wavefront over the product's own 4-wide BVH, closest child
+       MPT_PIPE_ORDERED = 3,    /* the same wave-local wavefront over the product's own 4-wide BVH, closest child
                                    first, with the reference-order walk for the rays whose answer could depend on the
                                    order (same image bit for bit; falls back to pipeline 2 when a scene's child boxes
                                    are not nested in their parents' or it has more than 16 spheres)                  */
+       MPT_PIPE_AUTO = 4 };     /* pipeline 3 for scenes of MPT_AUTO_ORDERED_PRIMS (16384) primitives or more — where it
+                                   is 1.2-1.7x faster — and pipeline 2 below that, where the two are level (scene.xml:
+                                   27.1 ms either way, pipeline 2 overlaps consecutive renders slightly better)        */
+#define MPT_AUTO_ORDERED_PRIMS 16384u
 
 typedef struct mpt_render_params {
     int32_t rng_mode;        /* MPT_RNG_*                                                             */
@@ -183,7 +187,7 @@ int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 
 /* BVH construction on the GPU — stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,
  * 195-317: sequential full-sweep SAH, 8.2 s for 1 M primitives): a linear BVH (63-bit Morton codes, radix sort, Karras'
- * radix tree, bottom-up refit) with leaves of <= 8 primitives, written in the REFERENCE's buffer format so that
+ * radix tree, bottom-up refit) with leaves of <= 4 primitives (MPT_LBVH_LEAF: 1..8), written in the REFERENCE's buffer format so that
  * mpt_upload_scene (and the reference's shader, and the oracle) can consume it: bvh_out = 2 float4 per node as
  * Scene::createBVHBuffer returns them (root = node 0), prim_idx_out = Scene::createPrimitiveIndexBuffer.
  * prims: the 3-float4-per-primitive array of Scene::createTransformsBuffer (host memory, already sorted spheres first as

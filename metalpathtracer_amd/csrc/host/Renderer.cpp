@@ -35,7 +35,7 @@ Renderer::Renderer(int deviceOrdinal, const std::string& scenePath, const std::s
     params_.rng_mode = MPT_RNG_LITERAL;  // what the reference's shader does
     params_.bsdf_mode = MPT_BSDF_LAMBERT;
     params_.max_depth = 32;              // R/Renderer/Shaders/PathTracing.h:216
-    params_.pipeline = MPT_PIPE_ORDERED;
+    params_.pipeline = MPT_PIPE_AUTO;
     params_.sample_count = 1;
     params_.seed_lo = 1;
     params_.shard_count = 1;

@@ -20,7 +20,7 @@ static void usage() {
     std::puts(
         "mpt_render --scene scene.xml [--asset-root DIR] [--width 1280] [--height 720]\n"
         "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter]\n"
-        "           [--pipeline ordered|wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
+        "           [--pipeline auto|ordered|wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
         "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
         "           [--gpus N] [--camera-path FILE [--out-dir runs]]\n"
         "  --frames N        run the reference's frame protocol (N draw() calls, running mean) instead of batch spp\n"
@@ -191,7 +191,7 @@ int main(int argc, char** argv) {
     std::memset(&prm, 0, sizeof prm);
     prm.rng_mode = MPT_RNG_PHILOX;
     prm.shard_count = 1;
-    prm.pipeline = MPT_PIPE_ORDERED;
+    prm.pipeline = MPT_PIPE_AUTO;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* {
@@ -231,7 +231,8 @@ int main(int argc, char** argv) {
             const char* v = next();
             prm.pipeline = std::strcmp(v, "megakernel") == 0 ? MPT_PIPE_MEGAKERNEL
                            : std::strcmp(v, "wavefront") == 0 ? MPT_PIPE_WAVEFRONT
-                           : std::strcmp(v, "wavelocal") == 0 ? MPT_PIPE_WAVELOCAL : MPT_PIPE_ORDERED;
+                           : std::strcmp(v, "wavelocal") == 0 ? MPT_PIPE_WAVELOCAL
+                           : std::strcmp(v, "ordered") == 0 ? MPT_PIPE_ORDERED : MPT_PIPE_AUTO;
         }
         else {
             usage();

@@ -962,7 +962,7 @@ static int check_ready(mpt_ctx* ctx, const mpt_render_params* p) {
     if ((uint32_t)ctx->u.screenSize[0] != ctx->W || (uint32_t)ctx->u.screenSize[1] != ctx->H)
         return fail(ctx, MPT_ERR_INVALID_ARG, "uniforms.screenSize does not match mpt_resize");
     if (p->rng_mode < 0 || p->rng_mode > 1 || p->bsdf_mode < 0 || p->bsdf_mode > 1 || p->max_depth < 1 ||
-        p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 3 || p->shard_count < 1 || p->shard_rank < 0 ||
+        p->max_depth > 31 + 1 || p->pipeline < 0 || p->pipeline > 4 || p->shard_count < 1 || p->shard_rank < 0 ||
         p->shard_rank >= p->shard_count || (uint64_t)p->sample_begin + p->sample_count > (1ull << 27))
         return fail(ctx, MPT_ERR_INVALID_ARG, "bad render params");
     return MPT_OK;
@@ -998,7 +998,9 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
 
     // the closest-first pipeline needs nested boxes and few spheres (mpt_upload_scene); otherwise the reference-order
     // wave-local pipeline renders the same image
-    const int pipeline = p->pipeline == MPT_PIPE_ORDERED && !ctx->acc_ok ? MPT_PIPE_WAVELOCAL : p->pipeline;
+    int pipeline = p->pipeline;
+    if (pipeline == MPT_PIPE_AUTO) pipeline = ctx->n_prims >= MPT_AUTO_ORDERED_PRIMS ? MPT_PIPE_ORDERED : MPT_PIPE_WAVELOCAL;
+    if (pipeline == MPT_PIPE_ORDERED && !ctx->acc_ok) pipeline = MPT_PIPE_WAVELOCAL;
     pp.scene = scene_dev(ctx);
     pp.q[0] = L.q[0];
     pp.q[1] = L.q[1];
@@ -1566,7 +1568,9 @@ extern "C" int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims,
         if (bvh_capacity_nodes < 2 * n_prims - 1) return fail(ctx, MPT_ERR_INVALID_ARG, "bvh_out must hold 2 * n_prims - 1 nodes");
         HIPCHK(hipSetDevice(ctx->device));
         float ms = 0.0f;
-        hipError_t e = mpt_lbvh::build(ctx->stream, prims, (uint32_t)n_prims, bvh_out, n_nodes_out, prim_idx_out, &ms);
+        int leaf_max = 4;
+        if (const char* lm = getenv("MPT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
+        hipError_t e = mpt_lbvh::build(ctx->stream, prims, (uint32_t)n_prims, leaf_max, bvh_out, n_nodes_out, prim_idx_out, &ms);
         if (e != hipSuccess) return fail(ctx, MPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
         if (device_ms_out) *device_ms_out = ms;
         return MPT_OK;

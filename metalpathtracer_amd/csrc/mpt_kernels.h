@@ -492,6 +492,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
     uint32_t grp = blockIdx.x & (MPT_NGROUP - 1u);     // range this wave currently claims from
     uint32_t seen = 0;                                 // cursor value (virtual index) at this wave's previous claim
     bool exhausted = false;
+    uint32_t tile_cached = 0xFFFFFFFFu, tile_xy_cached = 0u;
     uint32_t n_rays = 0, n_paths = 0;
     WorkCount wc = {};
 #ifdef MPT_DEBUG_WAVE_TIMES
@@ -591,10 +592,26 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         bool fresh = false;  // this lane starts a new closest-hit query (primary ray or ring-0 record)
         if (level < 0) {
             fresh = true;
-            ps.path = range_chunk_to_path_chunk(pp, cur >> 6, grp) * 64u + lane;  // cur is a virtual index of range grp
+            // 64 new paths = one 8x8 pixel tile at one sample index: everything about the tile is wave-uniform, and its
+            // table entry is kept from the previous primary step (the steps of a claim walk the samples of one tile) —
+            // a dependent vector load from L2 at the head of every primary step otherwise
+            const uint32_t pchunk = range_chunk_to_path_chunk(pp, cur >> 6, grp);  // cur is a virtual index of range grp
             cur += 64u;
-            uint32_t px, py, sidx;
-            if (path_to_pixel(pp, ps.path, px, py, sidx)) {
+            uint32_t tl, sidx;
+            if (pp.s_shift != 0xFFu) {
+                tl = pchunk >> pp.s_shift;
+                sidx = pchunk & (pp.S - 1u);
+            } else {
+                tl = pchunk / pp.S;
+                sidx = pchunk - tl * pp.S;
+            }
+            if (tl != tile_cached) {
+                tile_cached = tl;
+                tile_xy_cached = (uint32_t)__builtin_amdgcn_readfirstlane((int)pp.tile_xy[tl]);
+            }
+            ps.path = pchunk * 64u + lane;
+            const uint32_t px = (tile_xy_cached & 0xFFFFu) * 8u + (lane & 7u), py = (tile_xy_cached >> 16) * 8u + (lane >> 3);
+            if (px < pp.width && py < pp.height) {
                 gen_primary(pp, px, py, pp.sample_begin + sidx, ps, g);
                 valid = true;
                 n_paths++;

@@ -1,6 +1,7 @@
 // mpt_lbvh.h — BVH construction ON THE GPU: a linear BVH (63-bit Morton codes of the primitive
-// centroids, radix sort, Karras' parallel radix-tree construction, bottom-up refit) collapsed to leaves of <= 8
-// primitives and written in the REFERENCE's buffer format (SURVEY App. D buf 0 / buf 6):
+// centroids, radix sort, Karras' parallel radix-tree construction, bottom-up refit) collapsed to leaves of <= 4
+// primitives (MPT_LBVH_LEAF = 1..8; the closest-first pipeline tests every primitive of a leaf it enters, so small
+// leaves pay there) and written in the REFERENCE's buffer format (SURVEY App. D buf 0 / buf 6):
 //   node = (bmin.xyz, bits(leftFirst)) (bmax.xyz, bits(count));  count > 0: leaf, primitiveIndices[leftFirst ..
 //   leftFirst+count);  count <= 0: internal, left child = leftFirst, right child = -count;  root = node 0.
 // It stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,195-317: a sequential
@@ -18,7 +19,7 @@
 #include <algorithm>
 #include <vector>
 
-#define MPT_LBVH_LEAF 8u
+#define MPT_LBVH_LEAF_MAX 8u   // what the reference's builder allows (R/Scene/Scene.h:223) and a device leaf record holds twice over
 
 namespace mpt_lbvh {
 
@@ -73,10 +74,14 @@ __global__ void k_morton(const float4* blo, const float4* bhi, uint32_t n, const
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned long long code = 0;
+    // cubic cells: the same scale on all three axes (the largest extent of the centroid bounds).  Per-axis scaling made
+    // the cells of scene.xml-like scenes — a ground sphere centred 10^4 below everything else — 125 times taller than
+    // wide, so that Morton neighbours were columns of triangles far apart in y (leaves of 3x the area, 3x the tests).
+    const float ext = fmaxf(ord2f(cb[3]) - ord2f(cb[0]), fmaxf(ord2f(cb[4]) - ord2f(cb[1]), ord2f(cb[5]) - ord2f(cb[2])));
     for (int a = 0; a < 3; ++a) {
-        const float mn = ord2f(cb[a]), mx = ord2f(cb[3 + a]);
+        const float mn = ord2f(cb[a]);
         const float lo = a == 0 ? blo[i].x : a == 1 ? blo[i].y : blo[i].z, hi = a == 0 ? bhi[i].x : a == 1 ? bhi[i].y : bhi[i].z;
-        const float c = 0.5f * lo + 0.5f * hi, ext = mx - mn;
+        const float c = 0.5f * lo + 0.5f * hi;
         float u = ext > 0.0f ? (c - mn) / ext : 0.0f;
         u = isfinite(u) ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;
         const unsigned long long q = (unsigned long long)fminf(u * 2097152.0f, 2097151.0f);
@@ -154,14 +159,14 @@ __global__ void k_refit(const uint32_t* vals, const float4* blo, const float4* b
 // which radix-tree nodes become nodes of the output: an internal node spanning more than LEAF primitives stays internal;
 // a node (internal or single primitive) spanning <= LEAF primitives whose parent spans more becomes a leaf
 __device__ __forceinline__ int span(const int2* range, int n, int node) { return node >= n - 1 ? 1 : range[node].y - range[node].x + 1; }
-__global__ void k_mark(int n, const int* parent, const int2* range, uint32_t* keep) {
+__global__ void k_mark(int n, int leaf_max, const int* parent, const int2* range, uint32_t* keep) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
     if (node >= 2 * n - 1) return;
     const int sz = span(range, n, node), par = parent[node];
-    const bool k = sz > (int)MPT_LBVH_LEAF || par < 0 || span(range, n, par) > (int)MPT_LBVH_LEAF;
+    const bool k = sz > leaf_max || par < 0 || span(range, n, par) > leaf_max;
     keep[node] = k ? 1u : 0u;
 }
-__global__ void k_emit(int n, const int2* child, const int2* range, const uint32_t* keep, const uint32_t* index, const float4* nlo,
+__global__ void k_emit(int n, int leaf_max, const int2* child, const int2* range, const uint32_t* keep, const uint32_t* index, const float4* nlo,
                        const float4* nhi, const uint32_t* vals, float4* bvh_out, int* prim_idx_out) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
     if (node < n) prim_idx_out[node] = (int)vals[node];  // primitiveIndices = the sorted order
@@ -169,7 +174,7 @@ __global__ void k_emit(int n, const int2* child, const int2* range, const uint32
     const uint32_t at = index[node];
     const int sz = span(range, n, node);
     int lf, cnt;
-    if (sz > (int)MPT_LBVH_LEAF) {
+    if (sz > leaf_max) {
         lf = (int)index[child[node].x];
         cnt = -(int)index[child[node].y];
     } else {
@@ -198,7 +203,7 @@ struct Scratch {  // freed on every exit path
 
 // prims: host, 12 floats per primitive (Scene::createTransformsBuffer).  bvh_out: host, room for 8 * (2n - 1) floats;
 // prim_idx_out: host, n ints.  Returns hipSuccess and the node count, or the failing HIP status.
-static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, float* bvh_out, uint64_t* n_nodes_out,
+static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int leaf_max, float* bvh_out, uint64_t* n_nodes_out,
                         int32_t* prim_idx_out, float* ms_out) {
 #define MPT_LB(call)                       \
     do {                                   \
@@ -259,14 +264,14 @@ static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, floa
         }
         hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, stream, (const uint32_t*)vals2, (const float4*)blo, (const float4*)bhi, (int)n,
                            (const int2*)child, (const int*)parent, nlo, nhi, arrived);
-        hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, (const int*)parent, (const int2*)range, keep);
+        hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int*)parent, (const int2*)range, keep);
         size_t scan_bytes = 0;
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, index, (int)nn + 1, stream));
         char* tmp2;
         MPT_LB(sc.alloc(&tmp2, scan_bytes));
         MPT_LB(hipMemsetAsync(keep + nn, 0, 4, stream));
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, scan_bytes, keep, index, (int)nn + 1, stream));
-        hipLaunchKernelGGL(k_emit, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child, (const int2*)range, (const uint32_t*)keep,
+        hipLaunchKernelGGL(k_emit, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int2*)child, (const int2*)range, (const uint32_t*)keep,
                            (const uint32_t*)index, (const float4*)nlo, (const float4*)nhi, (const uint32_t*)vals2, d_bvh, d_idx);
         MPT_LB(hipGetLastError());
         MPT_LB(hipEventRecord(e1, stream));

@@ -184,6 +184,7 @@ def test_bunny20_full_size_properties(gpu_ctx):
     gpu_ctx.clear_sum()
     gpu_ctx.render(sample_count=4, **kw)
     _same(a, gpu_ctx.read_sum())                                                  # deterministic
+    assert gpu_ctx.stats()["tree_parked"] > 0                                     # AUTO chose the closest-first pipeline
     gpu_ctx.clear_sum()
     gpu_ctx.render(sample_count=4, pipeline=capi.PIPE_WAVELOCAL, **kw)
     _same(a, gpu_ctx.read_sum())                                                  # closest-first == reference order

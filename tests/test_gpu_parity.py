@@ -566,12 +566,14 @@ def test_randomised_cases_bit_exact():
     assert "60 cases, 0 mismatches" in r.stdout
 
 
-def test_headline_config_is_bit_identical_to_the_oracle():
+@pytest.mark.parametrize("pipe", ["4", "3"])
+def test_headline_config_is_bit_identical_to_the_oracle(pipe):
     """BASELINE.json configs[1] itself — scene.xml, 1920x1080, 256 spp, depth 8 (890,385,105 rays): every float of the
-    HDR sum equals the oracle's (tests/gpu_headline_parity.py, default pipeline = closest-first; the oracle takes ~8 s on the GPU box's 16 host threads)."""
+    HDR sum equals the oracle's (tests/gpu_headline_parity.py; the oracle takes ~8 s on the GPU box's 16 host threads).
+    Once with the default pipeline choice (AUTO = what bench.py runs), once with the closest-first pipeline."""
     import os, subprocess, sys
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_headline_parity.py")], capture_output=True,
-                       text=True, timeout=1200)
+                       text=True, timeout=1200, env=dict(os.environ, PIPE=pipe))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "bit-identical=True" in r.stdout and "890385105 rays" in r.stdout
