@@ -54,7 +54,7 @@ static WaveBudgets default_budgets() {
 // and the number of lanes that must still be walking for a step to go on (MPT_OT_MIN_ACTIVE).
 static OtBudgets default_ot_budgets() {
     OtBudgets b;
-    const uint32_t ladder[] = {12, 32, 80, 200, 500};  // measured on scene.xml / bunny x20: 4,10 -> 29.3 / 123 ms, 12,32 -> 28.1 / 113, 24,64 -> 28.4 / 115
+    const uint32_t ladder[] = {16, 48, 120, 300, 750};  // measured on scene.xml / bunny x20: 4,10 -> 29.3 / 123 ms, 12,32 -> 28.1 / 113, 16,48 -> 27.4 / 111, 24,64 -> 28.4 / 115
     for (uint32_t k = 0; k < MPT_OT_MLEVELS; ++k) {
         b.trips[k] = k + 1 < MPT_OT_MLEVELS && k < 5 ? ladder[k] : 0x7FFFFFFFu;
         b.min_active[k] = k == 0 ? 0 : 24;

@@ -26,8 +26,7 @@
 //   ring M_k step  64 rays that all have to walk the tree: closest-first walk (LDS stack) for the ring's budget of node-loop
 //                  trips; unfinished walks are parked in ring M_k+1 with their state (next node, stack, best t /
 //                  primitive): rays sorted by the walk they have behind them meet rays of similar length (lane
-//                  utilisation of the walk 25 % -> 50 %).  Misses are shaded at once, hits go to ring H
-//   ring H step    64 hits in the tree: final check, hit point / normal / material, Philox, BSDF -> bounce rays to ring R
+//                  utilisation of the walk 25 % -> 50 %).  Finished rays: final check, one bounce of shading, survivors -> R
 //   ring E step    reference-order walk + shading for the flagged rays (6.5e-4 of the rays)
 #pragma once
 #include "mpt_device.h"
@@ -46,7 +45,7 @@
 #ifndef MPT_OT_MLEVELS
 #define MPT_OT_MLEVELS 3u                 // tree-walk rings: rays sorted by the walk they have already done (budgets)
 #endif
-#define MPT_OT_RINGS (3u + MPT_OT_MLEVELS) // R fresh rays, H hits to shade, E reference-order walk, M0.. rays walking the tree
+#define MPT_OT_RINGS (2u + MPT_OT_MLEVELS) // R fresh rays, E reference-order walk, M0.. rays walking the tree
 #define MPT_OT_PARK 8u                    // stack entries a parked ray takes along (>= the LDS stack depth)
 #ifndef MPT_OT_EARLY
 #define MPT_OT_EARLY 8u                   // the node loop pauses when fewer than 1/EARLY of the lanes that entered it still search
@@ -310,6 +309,8 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
         while (cur < MPT_OT_LEAF && (!BUDGETED || trips < budget)) {
             // few lanes still searching, the others hold a leaf: test the leaves now, the search resumes afterwards
             if ((uint32_t)__popcll(__ballot(true)) * MPT_OT_EARLY < n_entered) break;
+            // (taking ONE source per trip for the whole wave — LDS only when every searching lane is at a staged node —
+            // instead of a per-lane choice was measured on bunny x20: no difference, 20.7 ms either way)
             const OtNode nd = ot_load_node<ALL_LDS>(ac, lds, cur);
             const float lim = ot_cull_limit(T, ac.eps_abs);
             uint32_t k0 = ot_box_key(r, nd.lx.x, nd.ly.x, nd.lz.x, nd.hx.x, nd.hy.x, nd.hz.x, nd.ref.x, lim, 0u);
@@ -480,9 +481,8 @@ __device__ __forceinline__ OtStack ot_stack(const AccelDev& ac, float4* lds_raw,
 
 // ---- the pipeline kernel ------------------------------------------------------------------------------------------
 #define MPT_OT_RING_R 0u
-#define MPT_OT_RING_H 1u
-#define MPT_OT_RING_E 2u
-#define MPT_OT_RING_M 3u       // M0 ... M(MLEVELS-1)
+#define MPT_OT_RING_E 1u
+#define MPT_OT_RING_M 2u       // M0 ... M(MLEVELS-1)
 #define MPT_OT_NONE 0xFFu
 
 template <bool COUNT, bool ALL_LDS>
@@ -517,7 +517,6 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         // ---- step choice: a full wave of the most advanced kind of work; else new paths; else what is left ----------------
         uint32_t kind = MPT_OT_NONE;  // ring to pop from; NONE = primary step
         if (cnt[MPT_OT_RING_E] >= 64u) kind = MPT_OT_RING_E;
-        else if (cnt[MPT_OT_RING_H] >= 64u) kind = MPT_OT_RING_H;
 #pragma unroll
         for (int k = (int)MPT_OT_RINGS - 1; k >= (int)MPT_OT_RING_M; --k)  // the longest walks first
             if (kind == MPT_OT_NONE && cnt[k] >= 64u) kind = (uint32_t)k;
@@ -561,8 +560,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 for (int k = (int)MPT_OT_RINGS - 1; k >= (int)MPT_OT_RING_M; --k)
                     if (kind == MPT_OT_NONE && cnt[k] != 0u) kind = (uint32_t)k;
                 if (kind == MPT_OT_NONE) {
-                    if (cnt[MPT_OT_RING_H] != 0u) kind = MPT_OT_RING_H;
-                    else if (cnt[MPT_OT_RING_R] != 0u) kind = MPT_OT_RING_R;
+                    if (cnt[MPT_OT_RING_R] != 0u) kind = MPT_OT_RING_R;
                     else if (cnt[MPT_OT_RING_E] != 0u) kind = MPT_OT_RING_E;
                     else break;
                 }
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 ps.d = f3(a.w, b.x, b.y);
                 ps.thr.x = b.z;
                 ps.thr.y = b.w;
-                if (kind != MPT_OT_RING_R && kind != MPT_OT_RING_E) {
+                if (kind >= MPT_OT_RING_M) {
                     const uint4 tv = ring.tv[at];
                     T = __uint_as_float(tv.x);
                     W = (int)tv.y;
@@ -675,15 +673,11 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                     ot_top_test<COUNT>(ac, lds, ps.o, ps.d, r, T, W, tie, need, wc);
                     if (tie) dest = MPT_OT_RING_E;
                     else if (need) dest = MPT_OT_RING_M;
-#ifndef MPT_OT_TOP_HITS_TO_RING_H
-                    // a sphere of the always list and nothing to walk: checked and shaded here (sending these hits through
-                    // ring H as well cost more in ring traffic than the divergence it removes: 28.7 -> 28.1 ms)
+                    // a sphere of the always list and nothing to walk: checked and shaded here ... or nothing hit: the sky.
+                    // (A ring of hits, shaded 64 at a time at full width, was tried and measured: the extra ring hop
+                    // costs more than the divergence of the hit branch — scene.xml 28.7 vs 28.1 ms, bunny x20 22.0 vs 21.2)
                     else if (W >= 0 && !ot_final_check(ac, pp.scene, lds, ps.o, ps.d, r, T, W)) dest = MPT_OT_RING_E;
-                    else shade = true;  // ... or nothing hit at all: the sky
-#else
-                    else if (W >= 0) dest = MPT_OT_RING_H;
                     else shade = true;
-#endif
                 }
             }
             OT_TOC(2);
@@ -718,17 +712,10 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                         walk_again = true;
                     }
                 }
-                else if (W >= 0) dest = MPT_OT_RING_H;
+                else if (W >= 0 && !ot_final_check(ac, pp.scene, lds, ps.o, ps.d, r, T, W)) dest = MPT_OT_RING_E;
                 else shade = true;
             }
             OT_TOC(3);
-        } else if (kind == MPT_OT_RING_H) {
-            // ---- hits: the final check decides between shading and the reference-order walk ---------------------------
-            if (valid) {
-                if (ot_final_check(ac, pp.scene, lds, ps.o, ps.d, r, T, W)) shade = true;
-                else dest = MPT_OT_RING_E;
-            }
-            OT_TOC(4);
         } else {
             // ---- reference-order walk (PathTracing.h:75-204 as closest_hit_resume restates it) ----------------------
             if (valid) {
@@ -763,7 +750,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 ring.dt[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
                 ring.tl[to] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
                 ring.ia[to] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
-                if (dest == MPT_OT_RING_H || dest >= MPT_OT_RING_M) {
+                if (dest >= MPT_OT_RING_M) {
                     // a ray parked by a top test starts its walk at the root (walk_cur = 0, walk_sp = 0 there)
                     ring.tv[to] = make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,
                                              walk_sp | (walk_lost ? 0x40000000u : 0u) | (walk_again ? 0x80000000u : 0u));
