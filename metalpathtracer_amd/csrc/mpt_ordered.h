@@ -43,13 +43,13 @@
 #endif
 #define MPT_OT_WGS_PER_CU ((MPT_OT_WAVES * 256) / MPT_OT_THREADS)   // workgroups that share a CU's 160 KiB of LDS
 #ifndef MPT_OT_MLEVELS
-#define MPT_OT_MLEVELS 3u                 // tree-walk rings: rays sorted by the walk they have already done (budgets)
-#endif
+#define MPT_OT_MLEVELS 2u                 // tree-walk rings: rays sorted by the walk they have already done (budgets).
+#endif                                    // bunny x20, 256 spp: 2 rings 76.8 ms, 3 rings 77.9, 4 rings 82.4
 #define MPT_OT_RINGS (2u + MPT_OT_MLEVELS) // R fresh rays, E reference-order walk, M0.. rays walking the tree
 #define MPT_OT_PARK 8u                    // stack entries a parked ray takes along (>= the LDS stack depth)
 #ifndef MPT_OT_EARLY
-#define MPT_OT_EARLY 8u                   // the node loop pauses when fewer than 1/EARLY of the lanes that entered it still search
-#endif
+#define MPT_OT_EARLY 4u                   // the node loop pauses when fewer than 1/EARLY of the lanes that entered it still search
+#endif                                    // (bunny x20: 1/2 79.3 ms, 1/3 77.9, 1/4 77.9, 1/8 79.5, 1/16 83.8)
 
 // Diagnostics build (-DMPT_OT_TIMES): shader-clock cycles per region of k_ordered, summed over all waves, plus step and
 // lane counts per step kind (tools/gpu_ot_times.py).  Not compiled into the product library.

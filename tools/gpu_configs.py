@@ -66,9 +66,10 @@ def main():
     sc, _ = load(os.path.join(ASSETS, "scene.xml"), host.BVH_REFERENCE_SWEEP)
     measure("cfg1 scene.xml 1920x1080x256 d8", sc, 1920, 1080, 256 // d, 8, capi.BSDF_LAMBERT, None, 1)
     measure("     scene.xml 1920x1080x256 d32", sc, 1920, 1080, 256 // d, 32, capi.BSDF_LAMBERT, None, 1)
-    for mode, tag in ((host.BVH_REFERENCE_SWEEP, "reference tree"), (host.BVH_BINNED_CENTROID, "binned tree")):
+    trees = ((host.BVH_REFERENCE_SWEEP, "reference tree"), (host.BVH_BINNED_CENTROID, "binned-SAH tree"), (host.BVH_GPU_LBVH, "GPU LBVH"))
+    for mode, tag in trees:
         sc, tb = load(os.path.join(ASSETS, "bunny20.xml"), mode)
-        print("bunny20 %s: %d prims, %d nodes, host build %.2f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
+        print("bunny20 %s: %d prims, %d nodes, build %.3f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
         measure("cfg2 bunny20 1920x1080x1024 d8, %s" % tag, sc, 1920, 1080, 1024 // d, 8, capi.BSDF_LAMBERT, None, 1, reps=1)
         measure("cfg3 bunny20 3840x2160x1024 d8, 1/8 tile shard, %s" % tag, sc, 3840, 2160, 1024 // d, 8, capi.BSDF_LAMBERT, None, 8, reps=1)
     tmp = tempfile.mkdtemp()
@@ -81,9 +82,9 @@ def main():
   <Sphere position="15,18,-10" radius="9" albedo="1,1,1" emission="0,0,0" materialType="1.5" emissionPower="0"/>
   <Sphere position="0,60,-20" radius="10" albedo="0,0,0" emission="1,0.9,0.7" materialType="0" emissionPower="5"/>
 </Scene>""" % (tmp, tmp))
-    for mode, tag in ((host.BVH_BINNED_CENTROID, "binned tree"), (host.BVH_REFERENCE_SWEEP, "reference tree")):
+    for mode, tag in trees:
         sc, tb = load(xml, mode)
-        print("1M-tri heightfields %s: %d prims, %d nodes, host build %.2f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
+        print("1M-tri heightfields %s: %d prims, %d nodes, build %.3f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
         measure("cfg4 1M tris glass+mirror 1920x1080x4096 d16, 1/8 tile shard, %s" % tag, sc, 1920, 1080, 4096 // d, 16,
                 capi.BSDF_SCATTER, None, 8, reps=1)
 

@@ -25,8 +25,8 @@ names = ["select/claim", "fetch (gen / ring load)", "top test", "walk", "final c
 print("%s %d spp: %.2f ms, %d rays, retraced %d, parked %d" % (name, spp, s["total_ms"], s["rays"], s["exact_retraces"], s["tree_parked"]))
 for n, c in zip(names, v[:8]):
     print("  %-26s %5.1f %%" % (n, 100.0 * c / tot))
-kinds = ["ring R (fresh rays)", "ring E (reference order)", "ring M0 (tree walk)", "ring M1", "ring M2", "primary"]
-for k in range(6):
+kinds = ["ring R (fresh rays)", "ring E (reference order)", "ring M0 (tree walk)", "ring M1", "primary"]
+for k in range(5):
     if v[8 + k]:
         print("  steps %-26s %10d  lanes/step %.1f" % (kinds[k], v[8 + k], v[16 + k] / v[8 + k]))
 w = v[24:29]
