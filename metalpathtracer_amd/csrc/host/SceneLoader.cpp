@@ -14,6 +14,8 @@
 //     (R/tiny_obj_loader.h:897-1038).  tests/test_ingest_vs_ref.py checks bit equality against the real library.
 #include "SceneLoader.h"
 
+#include "Transform.h"
+
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -580,15 +582,14 @@ SceneLoader::Status SceneLoader::Load(const std::string& path, Scene* scene, con
             if (!readable(resolved)) resolved = dirName(path) + "/" + baseName(given);
             Mesh mesh;
             if (!readObj(resolved, mesh, log)) result = MeshUnreadable;  // the reference carries on with no triangles
-            const float3 pos = vec3Attr(e.get("position"));
-            const float scale = floatAttr(e.get("scale"), 1.0f);
+            const Transform place(vec3Attr(e.get("position")), floatAttr(e.get("scale"), 1.0f));  // R/Scene/Transform.h:8-20
             const Material m = materialOf(e);
             for (const mpt::uint3& t : mesh.triangles) {
                 Primitive p;
                 p.type = PrimitiveType::Triangle;
-                p.data0 = pos + scale * mesh.vertices[t.x];
-                p.data1 = pos + scale * mesh.vertices[t.y];
-                p.data2 = pos + scale * mesh.vertices[t.z];
+                p.data0 = place.apply(mesh.vertices[t.x]);
+                p.data1 = place.apply(mesh.vertices[t.y]);
+                p.data2 = place.apply(mesh.vertices[t.z]);
                 p.material = m;
                 scene->addPrimitive(p);
             }

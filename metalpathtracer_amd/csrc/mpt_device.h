@@ -229,14 +229,19 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
             F3 oc = o - c;
             float a = dot3(d, d);
             float b = dot3(oc, d);
-            float cc = dot3(oc, oc) - radius * radius;
-            float disc = b * b - a * cc;
-            if (disc > 0.0f) {
-                float sq = sqrtf(disc);
-                float temp = (-b - sq) / a;
-                if (temp < best_t && temp > 0.0001f) {
-                    best_t = temp;
-                    best_prim = (int)(first + k);
+            // b >= 0 (the centre lies behind the ray): the root (-b - sqrt(disc)) / a is <= 0 whatever disc is and fails
+            // "> 0.0001" — signs are exact in floating point, so leaving before the square root and the division changes
+            // nothing (a NaN b compares false and takes the full path)
+            if (!(b >= 0.0f)) {
+                float cc = dot3(oc, oc) - radius * radius;
+                float disc = b * b - a * cc;
+                if (disc > 0.0f) {
+                    float sq = sqrtf(disc);
+                    float temp = (-b - sq) / a;
+                    if (temp < best_t && temp > 0.0001f) {
+                        best_t = temp;
+                        best_prim = (int)(first + k);
+                    }
                 }
             }
         }

@@ -220,12 +220,18 @@ __device__ __forceinline__ void ot_test_prim(const Prim3& pr, uint32_t index, F3
         const F3 oc = o - c;
         const float a = dot3(d, d);
         const float b = dot3(oc, d);
-        const float cc = dot3(oc, oc) - radius * radius;
-        const float disc = b * b - a * cc;
-        if (disc > 0.0f) {
-            const float sq = sqrtf(disc);
-            tt = (-b - sq) / a;
-            hit = tt > 0.0001f;
+        // b >= 0: the centre lies behind the ray.  Then -b <= 0 and sqrt >= 0, so the root (-b - sqrt(disc)) / a is <= 0
+        // and fails "> 0.0001" whatever disc is — signs are exact in floating point, so skipping the square root and
+        // the division here changes nothing (a NaN b compares false and takes the full path).  Bounce rays leaving the
+        // ground and every ray looking away from a sphere take this exit, usually as a whole wave.
+        if (!(b >= 0.0f)) {
+            const float cc = dot3(oc, oc) - radius * radius;
+            const float disc = b * b - a * cc;
+            if (disc > 0.0f) {
+                const float sq = sqrtf(disc);
+                tt = (-b - sq) / a;
+                hit = tt > 0.0001f;
+            }
         }
     }
     if (hit) {
