@@ -192,7 +192,7 @@ int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 
 /* BVH construction on the GPU — stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,
  * 195-317: sequential full-sweep SAH, 8.2 s for 1 M primitives): a linear BVH (63-bit Morton codes, radix sort, Karras'
- * radix tree, bottom-up refit) with leaves of <= 4 primitives (MPT_LBVH_LEAF: 1..8), written in the REFERENCE's buffer format so that
+ * radix tree, bottom-up refit) with leaves of <= 2 primitives (MPT_LBVH_LEAF: 1..8), written in the REFERENCE's buffer format so that
  * mpt_upload_scene (and the reference's shader, and the oracle) can consume it: bvh_out = 2 float4 per node as
  * Scene::createBVHBuffer returns them (root = node 0), prim_idx_out = Scene::createPrimitiveIndexBuffer.
  * prims: the 3-float4-per-primitive array of Scene::createTransformsBuffer (host memory, already sorted spheres first as

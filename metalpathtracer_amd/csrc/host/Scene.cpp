@@ -182,7 +182,12 @@ struct BuildContext {
         const Box bounds = rangeBox(start, end);
         const int self = emitLeaf(out, start, end, bounds);
         const size_t n = end - start;
-        if (n <= 4) return self;
+        static const size_t leafMax = [] {
+            const char* e = std::getenv("MPT_BINNED_LEAF");
+            const long v = e ? std::atol(e) : 2;   // bunny x20, closest-first pipeline: 12.15 / 12.26 / 12.28 / 11.16 Grays/s with 4 / 3 / 2 / 1
+            return static_cast<size_t>(v < 1 ? 1 : (v > 8 ? 8 : v));
+        }();
+        if (n <= leafMax) return self;
         Box cb;
         for (size_t i = start; i < end; ++i) cb.grow(cen[order[i]], cen[order[i]]);
         constexpr int BINS = 16;
@@ -231,11 +236,11 @@ struct BuildContext {
         }
         size_t mid;
         if (bestAxis < 0) {
-            if (n <= 8) return self;
+            if (n <= 2 * leafMax) return self;
             mid = start + n / 2;  // all centroids coincide: split the list
         } else {
             const float leafCost = boxArea(bounds.lo, bounds.hi) * n;
-            if (n <= 8 && bestCost >= leafCost) return self;
+            if (n <= 2 * leafMax && bestCost >= leafCost) return self;
             const float cmin = cb.lo[bestAxis], scale = BINS / (cb.hi[bestAxis] - cmin);
             auto it = std::partition(order.begin() + start, order.begin() + end, [&](size_t p) {
                 int b = static_cast<int>((cen[p][bestAxis] - cmin) * scale);

@@ -59,6 +59,7 @@ static OtBudgets default_ot_budgets() {
         b.trips[k] = k + 1 < MPT_OT_MLEVELS && k < 5 ? ladder[k] : 0x7FFFFFFFu;
         b.min_active[k] = k == 0 ? 0 : 24;
     }
+    b.inplace_min = 48;   // bunny x20 256 spp: never 74.9 ms, 56 72.6, 48 72.8, 40 73.1, 32 73.7, 24 74.4; scene.xml 25.96 / 25.6 / 25.6 / 25.7 / 25.9 / 26.6
     return b;
 }
 
@@ -280,6 +281,7 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
                 else if (k + 1 < MPT_OT_MLEVELS) ctx->ot_budgets.trips[k] = v < 1 ? 1 : v;
             }
         }
+    if ((e = getenv("MPT_OT_INPLACE")) && atoi(e) >= 1) ctx->ot_budgets.inplace_min = (uint32_t)atoi(e);
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 0;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
@@ -1568,7 +1570,7 @@ extern "C" int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims,
         if (bvh_capacity_nodes < 2 * n_prims - 1) return fail(ctx, MPT_ERR_INVALID_ARG, "bvh_out must hold 2 * n_prims - 1 nodes");
         HIPCHK(hipSetDevice(ctx->device));
         float ms = 0.0f;
-        int leaf_max = 4;
+        int leaf_max = 2;
         if (const char* lm = getenv("MPT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
         hipError_t e = mpt_lbvh::build(ctx->stream, prims, (uint32_t)n_prims, leaf_max, bvh_out, n_nodes_out, prim_idx_out, &ms);
         if (e != hipSuccess) return fail(ctx, MPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));

@@ -80,7 +80,8 @@ struct OtRings {              // [n_waves][MPT_OT_RINGS][MPT_WL_RING] records, s
 struct OtBudgets {
     uint32_t trips[MPT_OT_MLEVELS];       // node-loop trips a step of ring M_k may make (the last level: unlimited)
     uint32_t min_active[MPT_OT_MLEVELS];  // ... and it ends once fewer lanes than this are still walking
-};
+    uint32_t inplace_min;                 // a primary / ring-R step whose top test sends at least this many lanes into the tree
+};                                        // walks it at once (as a ring-M0 step would) instead of parking them; 65 = never
 
 struct AccelDev {
     const float4* nodes;    // 7 float4 per node, breadth-first (mpt_accel.h)
@@ -668,6 +669,8 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
 #endif
         uint32_t dest = MPT_OT_NONE;      // ring this lane's ray goes to next
         bool shade = false;               // ... or its closest hit is final: one bounce of shading now
+        uint32_t walk_kind = MPT_OT_NONE; // wave-uniform: the step walks the tree with this ring's budget
+        bool walking = false;             // ... and this lane takes part
         const OtRay r = ot_ray(ps.o, ps.d);
         if (kind == MPT_OT_NONE || kind == MPT_OT_RING_R) {
             // ---- TOP TEST: always-list spheres + the root's boxes ------------------------------------------------------
@@ -686,28 +689,40 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                     else shade = true;
                 }
             }
+            // most of the wave has to walk the tree: do it now, as a step of ring M0 would, and save those rays the trip
+            // through the ring (80 bytes written and read back per ray)
+            if ((uint32_t)__popcll(__ballot(dest == MPT_OT_RING_M)) >= budgets.inplace_min) {
+                walk_kind = MPT_OT_RING_M;
+                walking = dest == MPT_OT_RING_M;
+                if (walking) dest = MPT_OT_NONE;
+                else walk_cur = MPT_OT_DONE;
+            }
             OT_TOC(2);
         } else if (kind >= MPT_OT_RING_M) {
+            walk_kind = kind;
+            walking = valid;
+        }
+        if (walk_kind != MPT_OT_NONE) {
             // ---- closest-first walk, continued for this ring's budget of node-loop trips ------------------------------
             bool tie = false, done;
             uint32_t budget = 0u, min_active = 0u;
 #pragma unroll
             for (uint32_t k = 0; k < MPT_OT_MLEVELS; ++k)
-                if (kind == MPT_OT_RING_M + k) {
+                if (walk_kind == MPT_OT_RING_M + k) {
                     budget = budgets.trips[k];
                     min_active = budgets.min_active[k];
                 }
             // (the drain walks to the end: parking a handful of rays again and again does not pay)
-            if (!exhausted && (kind + 1u < MPT_OT_RINGS || min_active != 0u))
+            if (!exhausted && (walk_kind + 1u < MPT_OT_RINGS || min_active != 0u))
                 done = ot_walk<COUNT, true, ALL_LDS>(ac, pp.scene, lds, st, ps.o, ps.d, r, walk_cur, walk_sp, T, W, tie, walk_lost,
-                                                     kind + 1u < MPT_OT_RINGS ? budget : 0x7FFFFFFFu, min_active, wc);
+                                                     walk_kind + 1u < MPT_OT_RINGS ? budget : 0x7FFFFFFFu, min_active, wc);
             else
                 done = ot_walk<COUNT, false, ALL_LDS>(ac, pp.scene, lds, st, ps.o, ps.d, r, walk_cur, walk_sp, T, W, tie, walk_lost,
                                                       0xFFFFFFFFu, 0u, wc);
-            if (valid) {
-                load_rest();
+            if (walking) {
+                if (kind == walk_kind) load_rest();   // (a step of ring M; an in-place walk has everything in registers)
                 if (tie) dest = MPT_OT_RING_E;   // (whatever is left of the walk does not matter then)
-                else if (!done) dest = kind + 1u < MPT_OT_RINGS ? kind + 1u : kind;  // parked with its walk state
+                else if (!done) dest = walk_kind + 1u < MPT_OT_RINGS ? walk_kind + 1u : walk_kind;  // parked with its walk state
                 else if (walk_lost) {  // the stack dropped entries: once more from the root, now with the T found
                     if (walk_again) dest = MPT_OT_RING_E;
                     else {
@@ -722,7 +737,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 else shade = true;
             }
             OT_TOC(3);
-        } else {
+        } else if (kind == MPT_OT_RING_E) {
             // ---- reference-order walk (PathTracing.h:75-204 as closest_hit_resume restates it) ----------------------
             if (valid) {
                 uint32_t node = 0;
@@ -760,7 +775,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                     // a ray parked by a top test starts its walk at the root (walk_cur = 0, walk_sp = 0 there)
                     ring.tv[to] = make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,
                                              walk_sp | (walk_lost ? 0x40000000u : 0u) | (walk_again ? 0x80000000u : 0u));
-                    if (kind >= MPT_OT_RING_M && dest >= MPT_OT_RING_M) {
+                    if (walk_kind != MPT_OT_NONE) {   // (walk_sp = 0 for a ray that has not started)
 #pragma unroll
                         for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
                             if (walk_sp > 2u * k) {

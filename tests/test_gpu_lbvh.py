@@ -30,7 +30,7 @@ def _check_tree(bvh, idx, prims):
         depth_max = max(depth_max, depth[n])
         if cnt[n] > 0:
             leaves += 1
-            assert cnt[n] <= 4 and 0 <= lf[n] and lf[n] + cnt[n] <= P
+            assert cnt[n] <= 2 and 0 <= lf[n] and lf[n] + cnt[n] <= P
             covered[lf[n]:lf[n] + cnt[n]] += 1
             for k in range(cnt[n]):                                # the leaf box contains its primitives' boxes
                 p = prims[idx[lf[n] + k]]
@@ -91,4 +91,4 @@ def test_gpu_build_small_inputs_and_determinism(gpu_ctx):
         bvh2, idx2, _ = gpu_ctx.build_bvh(prims)
         np.testing.assert_array_equal(bvh.view(np.uint32), bvh2.view(np.uint32))
         np.testing.assert_array_equal(idx, idx2)
-        assert (n <= 4) == (bvh.shape[0] == 1)
+        assert (n <= 2) == (bvh.shape[0] == 1)                       # leaves hold <= 2 primitives by default
