@@ -262,6 +262,7 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
 #ifndef MPT_LEAF_EARLY
 #define MPT_LEAF_EARLY 8u
 #endif
+#define MPT_NODE_HOLD 0x80000000u   // hit link of a leaf record: HOLD | first << 4 | (count - 1)
 template <bool COUNT, bool ALL_LDS, bool BUDGETED>
 __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d, uint32_t& node,
                                                    float& best_t, int& best_prim, uint32_t budget, WorkCount& wc,
@@ -275,31 +276,44 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
     // the launch waiting for it.  The result of that walk is "miss"; return it without walking.  (The work counters
     // then lack this walk; the oracle, which restates the reference, makes it.)
     uint32_t i = (d.x != d.x || d.y != d.y || d.z != d.z) ? n_nodes : node;
-    uint32_t trips = 0;  // trips of the box-test loop this wave has made (kept equal in all lanes, see below)
+    // The box-test loop is written for the SCALAR unit: one per CU, shared by the four SIMDs, and as busy as the vector
+    // units in this kernel (rocprofv3: 0.50 SALU per VALU instruction; a loop with per-lane exits costs ~28 scalar
+    // instructions of exec-mask bookkeeping per trip).  So the loop is wave-uniform — every lane runs every trip, lanes
+    // that are not searching compute on a clamped node and discard — and a lane's state is one integer:
+    //   i < n_nodes           searching: the node to test next
+    //   i = HOLD | enc        holds a leaf (a leaf record's hit link IS that word); `skip` = where to go after it
+    //   n_nodes <= i < HOLD   done
+    // per trip: one compare for "searching", one v_cndmask for the link, two to commit — ~6 scalar instructions.
+    uint32_t trips = 0;  // trips of the box-test loop this wave has made in this call (wave-uniform)
     MPT_TIC(tic_);
     for (;;) {
-        uint32_t leaf_first = 0, leaf_count = 0;
-        const uint32_t n_entered = (uint32_t)__popcll(__ballot(i < n_nodes && (!BUDGETED || trips < budget)));
+        uint32_t skip = 0;
+        // (at least 1: "no lane searching" then leaves the loop by the same comparison as the early leave below)
+        const uint32_t n_entered0 = (uint32_t)__popcll(__ballot(i < n_nodes)), n_entered = max(n_entered0, 1u);
 #ifdef MPT_DEBUG_WAVE_TIMES
-        uint32_t my_trips = 0;
+        uint32_t my_trips = 0, round_trips = 0;
 #endif
-        while (i < n_nodes && (!BUDGETED || trips < budget)) {
-#ifdef MPT_DEBUG_WAVE_TIMES
-            my_trips++;
-#endif
+        uint32_t n_searching = n_entered0;
+        while (n_searching * MPT_LEAF_EARLY >= n_entered && (!BUDGETED || trips < budget)) {
+            const bool searching = i < n_nodes;
             // When fewer than 1/8 of the lanes that entered this search are still looking for their next leaf, the
             // others — who hold a leaf — stop waiting: the leaf phase runs now and the searchers resume afterwards
             // from where they are (each lane still sees its own sequence of tests).  In the deep rings most box-loop
             // lane slots were such waits (utilisation 19-42 %); 28.7 -> 27.4 ms, thresholds 1/6 .. 1/32 all help.
-            if ((uint32_t)__popcll(__ballot(true)) * MPT_LEAF_EARLY < n_entered) break;
+            // (this is the loop condition)
+#ifdef MPT_DEBUG_WAVE_TIMES
+            my_trips += searching ? 1u : 0u;
+            round_trips++;
+#endif
+            const uint32_t j = i < n_nodes - 1u ? i : n_nodes - 1u;
             float4 n0, n1;
-            if (ALL_LDS || i < n_lds) {
-                const v4f a = lds_nodes[2 * i], b = lds_nodes[2 * i + 1];
+            if (ALL_LDS || j < n_lds) {
+                const v4f a = lds_nodes[2 * j], b = lds_nodes[2 * j + 1];
                 n0 = make_float4(a.x, a.y, a.z, a.w);
                 n1 = make_float4(b.x, b.y, b.z, b.w);
             } else {
-                n0 = sc.nodes[2 * i];
-                n1 = sc.nodes[2 * i + 1];
+                n0 = sc.nodes[2 * j];
+                n1 = sc.nodes[2 * j + 1];
             }
             // PathTracing.h:52-72 slab test with tMin = 1e-4, tMax = best t.  The per-axis early-outs
             // are equivalent to one test after the third axis (tMin only grows, tMax only shrinks).
@@ -315,42 +329,35 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
             lo = fmaxf(lo, idz < 0.0f ? t1 : t0);
             hi = fminf(hi, idz < 0.0f ? t0 : t1);
             const bool box = hi > lo;
-            const int A = __float_as_int(n0.w), B = __float_as_int(n1.w);
+            const uint32_t A = __float_as_uint(n0.w), B = __float_as_uint(n1.w);  // links: box hit / box missed
             if (COUNT) {
-                wc.node_visits++;
-                wc.aabb_hits += box ? 1u : 0u;
+                wc.node_visits += searching ? 1u : 0u;
+                wc.aabb_hits += (searching && box) ? 1u : 0u;
                 if (first_active_lane()) wc.node_iters++;
             }
+            const uint32_t next = box ? A : B;
+            i = searching ? next : i;
+            skip = searching ? B : skip;
             if (BUDGETED) trips++;
-            if (B >= 0) {
-                i = box ? (uint32_t)A : (uint32_t)B;
-            } else {
-                i = (uint32_t)A;
-                if (box) {
-                    const uint32_t enc = (uint32_t)(-(B + 1));
-                    leaf_first = enc >> 4;
-                    leaf_count = (enc & 15u) + 1u;
-                    break;
-                }
-            }
+            n_searching = (uint32_t)__popcll(__ballot(i < n_nodes));
         }
-        // a lane that left the loop early (leaf found / done) adopts the trips the rest of the wave made meanwhile
-        if (BUDGETED) trips = wave_max_u32(trips);
 #ifdef MPT_DEBUG_WAVE_TIMES
         if (COUNT) {
-            const uint32_t round_trips = wave_max_u32(my_trips);
-            if (leaf_count != 0u) wc.wait_leaf += round_trips - my_trips;
+            if ((i & MPT_NODE_HOLD) != 0u) wc.wait_leaf += round_trips - my_trips;
             else wc.wait_done += round_trips - my_trips;   // finished, out of budget, or cut by the early leave
         }
 #endif
         MPT_TOC(wc.t_box, tic_);
-        if (leaf_count != 0u) {
+        if ((i & MPT_NODE_HOLD) != 0u) {
+            const uint32_t enc = i & ~MPT_NODE_HOLD;
             if (COUNT && first_active_lane()) wc.outer_iters++;
-            leaf_test<COUNT>(sc, lds_nodes, leaf_first, leaf_count, o, d, best_t, best_prim, wc);
+            leaf_test<COUNT>(sc, lds_nodes, enc >> 4, (enc & 15u) + 1u, o, d, best_t, best_prim, wc);
+            i = skip;
         }
         MPT_TOC(wc.t_leaf, tic_);
         // the wave goes round again only while some lane still has nodes to visit and budget is left ...
-        const unsigned long long going = __ballot(i < n_nodes && (!BUDGETED || trips < budget));
+        if (BUDGETED && trips >= budget) break;
+        const unsigned long long going = __ballot(i < n_nodes);
         if (going == 0ull) break;
         // ... and, in a budgeted step, while enough lanes are still working: the stragglers of a step are parked and
         // meet other stragglers in the next ring instead of holding 64 lanes for their long walks

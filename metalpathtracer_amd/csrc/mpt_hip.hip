@@ -663,9 +663,9 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         float* o = dnodes.data() + 8 * (size_t)i;
         memcpy(o, d.bmin, 12);
         memcpy(o + 4, d.bmax, 12);
-        if (d.leaf) {
-            o[3] = int_to_bits((int)inv[d.hit]);
-            o[7] = int_to_bits(-(int)(d.first * 16u + (d.count - 1u)) - 1);
+        if (d.leaf) {  // hit link = "hold this leaf" (MPT_NODE_HOLD | first << 4 | count - 1), miss link = the next node either way
+            o[3] = int_to_bits((int)(0x80000000u | (d.first * 16u + (d.count - 1u))));
+            o[7] = int_to_bits((int)inv[d.hit]);
         } else {
             o[3] = int_to_bits((int)inv[d.hit]);
             o[7] = int_to_bits((int)inv[d.miss]);

@@ -469,8 +469,14 @@ struct WaveBudgets {
 // the kernel was still latency-sensitive (FIFO rings, cached result slots); with the current kernel 6 waves/SIMD wins
 // there too (bunny x20 6.15 -> 6.82 Grays/s, 1 M triangles 4.40 -> 5.25).  7 waves/SIMD (896 threads, 72 VGPRs, waves
 // unevenly spread over the SIMDs) and 5 are worse than both.
-#define MPT_WL_THREADS(ALL_LDS) 768
-#define MPT_WL_WAVES(ALL_LDS) 6
+#ifndef MPT_WL_THREADS_N
+#define MPT_WL_THREADS_N 768
+#endif
+#ifndef MPT_WL_WAVES_N
+#define MPT_WL_WAVES_N 6
+#endif
+#define MPT_WL_THREADS(ALL_LDS) MPT_WL_THREADS_N
+#define MPT_WL_WAVES(ALL_LDS) MPT_WL_WAVES_N
 template <bool COUNT, bool ALL_LDS>
 __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) void k_wavelocal(PassParams pp, WaveRings ring, WaveBudgets budgets,
                                                                  uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {

@@ -2,7 +2,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 extra = sys.argv[2:]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I/root/repo/include",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-I/root/repo/include",
        "-I/root/repo/metalpathtracer_amd/csrc", "-c", src, "-o", "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"] + extra
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
