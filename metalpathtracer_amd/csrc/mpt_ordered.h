@@ -35,11 +35,17 @@
 #define MPT_OT_LEAF 0x80000000u
 #define MPT_OT_DONE 0xFFFFFFFFu
 #define MPT_OT_KEY_MISS 0x7F800000u       // +inf: sorts behind every hit
+// Operating point: five workgroups of 256 threads per CU = 5 waves/SIMD at 96 VGPRs (no scratch).  A workgroup's waves
+// must spread evenly over the four SIMDs — 4 waves = one per SIMD — or a second workgroup does not fit beside the first:
+// workgroups of 640 (10 waves: 3+3+2+2) "for 5 waves/SIMD" ran 40 % SLOWER than one workgroup of 1024, which is what
+// earlier occupancy experiments had measured without knowing why.  bunny x20 256 spp: 1024 x 1 (4 waves/SIMD) 72.5 ms,
+// 256 x 4 73.5, 256 x 5 65.5, 256 x 6 (80 VGPRs, 80 B of scratch) 65.3; the small workgroups stage less of the tree in
+// LDS (30 KB each instead of 160), which costs nothing measurable on the big scenes this pipeline is for.
 #ifndef MPT_OT_THREADS
-#define MPT_OT_THREADS 1024
+#define MPT_OT_THREADS 256
 #endif
 #ifndef MPT_OT_WAVES
-#define MPT_OT_WAVES 4                    // per SIMD: one 1024-thread workgroup per CU, up to 128 VGPRs
+#define MPT_OT_WAVES 5                    // per SIMD
 #endif
 #define MPT_OT_WGS_PER_CU ((MPT_OT_WAVES * 256) / MPT_OT_THREADS)   // workgroups that share a CU's 160 KiB of LDS
 #ifndef MPT_OT_MLEVELS

@@ -155,7 +155,7 @@ def test_million_triangle_config_matches_the_oracle(gpu_ctx, million_triangle_sc
     sc, buf = million_triangle_scene
     gpu_ctx.upload_scene(*buf)
     info = gpu_ctx.accel_info()
-    assert info["ordered_ok"] == 1 and info["nodes"] > info["lds_nodes"] > 100      # only the top of the tree fits LDS
+    assert info["ordered_ok"] == 1 and info["nodes"] > info["lds_nodes"] > 16       # only the top of the tree fits LDS (30 KB per workgroup)
     W, H, spp = 160, 90, 2
     u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount())
     gpu_ctx.resize(W, H)
