@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD = 1024          # 256 CUs x 4 SIMD-32; a wave64 VALU instruction occupies its SIMD for 2 cycles (same guide)
 MAX_CLOCK_GHZ = 2.4
+N_CU = 256             # one scalar unit per CU: one SALU instruction per cycle, shared by the four SIMDs
 B_QUEUE = 168.0        # compulsory wavefront-queue bytes per ray
 PIPE_NAMES = {0: "wavefront (global SoA queues)", 1: "megakernel", 2: "wave-local wavefront, reference-order walk",
               3: "wave-local wavefront, closest-first walk of the own 4-wide BVH"}
@@ -282,8 +283,14 @@ def main():
                 rf["traffic"] = hbm_bytes
                 rf["valu"] = {"achieved": valu_rate, "peak": valu_peak, "unit": "G wave64-instr/s", "frac": valu_frac,
                               "frac_at_2.4GHz": valu_rate / (N_SIMD * MAX_CLOCK_GHZ / 2.0), "instr_per_ray": prof["valu_per_ray"],
-                              "lane_utilisation": prof["lane_utilisation"], "useful_lane_frac": valu_frac * prof["lane_utilisation"],
+                              "lane_utilisation": prof["lane_utilisation"],
+                              "lane_utilisation_note": "exec-mask utilisation (SQ_THREAD_CYCLES_VALU / 64 SQ_INSTS_VALU): the "
+                                                       "box-test loop is wave-uniform, lanes that ride along count as active",
                               "salu_per_valu": prof["salu_per_ray"] / prof["valu_per_ray"], "clock_ghz": prof["clock_ghz"]}
+                # the scalar unit: one per CU, one instruction per cycle, shared by the CU's four SIMDs
+                salu_rate = prof["salu_per_ray"] * rays_per_launch / sec_per_launch / 1e9
+                rf["scalar"] = {"achieved": salu_rate, "peak": N_CU * prof["clock_ghz"], "unit": "G instr/s",
+                                "frac": salu_rate / (N_CU * prof["clock_ghz"])}
                 rf["hbm"] = {"achieved": hbm_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
                              "bytes_per_ray": prof["hbm_bytes_per_ray"], "l2_hit_rate": prof["l2_hit_rate"]}
                 rf["wave_cycles_split"] = prof["wave_cycles_split"]
