@@ -136,9 +136,14 @@ __device__ __forceinline__ bool path_to_pixel(const PassParams& pp, uint32_t pat
 }
 
 // Fragment.metal:29-42 — seed, sub-pixel jitter, primary ray.
-__device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, uint32_t sample,
+// (uvx, uvy): the pixel centre in [0,1]^2, Vertex.metal:5-17 — they depend on the pixel only, so k_wavelocal keeps them
+// across the primary steps of one tile (two IEEE divisions less per step)
+__device__ __forceinline__ void pixel_uv(const PassParams& pp, uint32_t px, uint32_t py, float& uvx, float& uvy) {
+    uvx = ((float)px + 0.5f) / pp.W;
+    uvy = ((float)py + 0.5f) / pp.H;
+}
+__device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, float uvx, float uvy, uint32_t sample,
                                             PathState& ps, PathRngDev& g) {
-    float uvx = ((float)px + 0.5f) / pp.W, uvy = ((float)py + 0.5f) / pp.H;  // Vertex.metal:5-17
     float xOff, yOff;
     g.pixel = py * pp.width + px;
     g.sample = sample;
@@ -162,6 +167,13 @@ __device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, u
     ps.L = f3(0, 0, 0);
     ps.La = 0.0f;
     ps.bounce = 0;
+}
+
+__device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, uint32_t sample,
+                                            PathState& ps, PathRngDev& g) {
+    float uvx, uvy;
+    pixel_uv(pp, px, py, uvx, uvy);
+    gen_primary(pp, px, py, uvx, uvy, sample, ps, g);
 }
 
 // literal RNG: the seed entering rayColor is a pure function of the pixel; recompute it for bounce rays
@@ -499,6 +511,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
     uint32_t seen = 0;                                 // cursor value (virtual index) at this wave's previous claim
     bool exhausted = false;
     uint32_t tile_cached = 0xFFFFFFFFu, tile_xy_cached = 0u;
+    float uvx_cached = 0.0f, uvy_cached = 0.0f;   // pixel_uv of this lane's pixel in the cached tile
     uint32_t n_rays = 0, n_paths = 0;
     WorkCount wc = {};
 #ifdef MPT_DEBUG_WAVE_TIMES
@@ -611,14 +624,16 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 tl = pchunk / pp.S;
                 sidx = pchunk - tl * pp.S;
             }
-            if (tl != tile_cached) {
+            const bool new_tile = tl != tile_cached;
+            if (new_tile) {
                 tile_cached = tl;
                 tile_xy_cached = (uint32_t)__builtin_amdgcn_readfirstlane((int)pp.tile_xy[tl]);
             }
             ps.path = pchunk * 64u + lane;
             const uint32_t px = (tile_xy_cached & 0xFFFFu) * 8u + (lane & 7u), py = (tile_xy_cached >> 16) * 8u + (lane >> 3);
+            if (new_tile) pixel_uv(pp, px, py, uvx_cached, uvy_cached);
             if (px < pp.width && py < pp.height) {
-                gen_primary(pp, px, py, pp.sample_begin + sidx, ps, g);
+                gen_primary(pp, px, py, uvx_cached, uvy_cached, pp.sample_begin + sidx, ps, g);
                 valid = true;
                 n_paths++;
             }
