@@ -7,7 +7,9 @@ run MPT_OT_BUDGETS=8
 run MPT_OT_BUDGETS=12
 run MPT_OT_BUDGETS=24
 run MPT_OT_BUDGETS=32
+run MPT_OT_INPLACE=24
 run MPT_OT_INPLACE=32
+run MPT_OT_INPLACE=40
 run MPT_OT_INPLACE=56
 run MPT_OT_INPLACE=65
 run MPT_OT_MIN_ACTIVE=0,16
