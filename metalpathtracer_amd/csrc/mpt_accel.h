@@ -226,9 +226,13 @@ static inline std::vector<float> emit(const Topology& tp, const std::vector<Item
         const Topology::WNode& w = tp.wn[i];
         float* o = out.data() + i * MPT_ACCEL_NODE_FLOATS;
         for (int c = 0; c < 4; ++c) {
+            const bool empty = w.child[c] == INT32_MIN;
             for (int a = 0; a < 3; ++a) {
-                o[4 * a + c] = w.cb[c].lo[a];
-                o[12 + 4 * a + c] = w.cb[c].hi[a];
+                // an empty slot is a box no walked ray can enter: both x planes at +inf put its x slab at [+inf, +inf] or
+                // [-inf, -inf] (1/d is finite and non-zero for every ray the walk takes, mpt_ordered.h ot_degenerate), so the
+                // device needs no "is there a child" test next to the slab test
+                o[4 * a + c] = empty ? (a == 0 ? INFINITY : 0.0f) : w.cb[c].lo[a];
+                o[12 + 4 * a + c] = empty ? (a == 0 ? INFINITY : 0.0f) : w.cb[c].hi[a];
             }
             uint32_t ref = MPT_ACCEL_EMPTY;
             if (w.child[c] >= 0) {

@@ -187,7 +187,10 @@ __device__ __forceinline__ uint32_t ot_box_key(const OtRay& r, float lx, float l
     t1 = fmaf(hz, r.idz, -r.oz);
     tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f);
     tf = fminf(tf, fmaxf(t0, t1));
-    const bool hit = ref != MPT_OT_DONE && tn <= tf * 1.00000048f && tn <= lim;
+    // one comparison: tn <= tf * (1 + 2^-21) and tn <= lim (no NaN here: planes and 1/d are finite for the rays the walk
+    // takes, or +inf for the x planes of an empty slot, which no ray enters — mpt_accel.h emit)
+    (void)ref;
+    const bool hit = tn <= fminf(tf * 1.00000048f, lim);
     return hit ? ((__float_as_uint(tn) & ~3u) | slot) : (MPT_OT_KEY_MISS | slot);
 }
 __device__ __forceinline__ void ot_sort2(uint32_t& a, uint32_t& b) {
