@@ -333,3 +333,29 @@ def test_closest_first_equals_reference_order_on_billions_of_rays(gpu_ctx):
         _same(img[capi.PIPE_WAVELOCAL], img[capi.PIPE_ORDERED])
         total += rays
     assert total > 5e9
+
+
+@pytest.mark.parametrize("inplace", ["1", "40", "65"])
+@pytest.mark.parametrize("name,bsdf", [("scene.xml", 0), ("glass.xml", 1), ("bunny20.xml", 0)])
+def test_walking_in_place_or_parking_gives_the_same_image(name, bsdf, inplace, monkeypatch):
+    """MPT_OT_INPLACE (read at mpt_create): a primary / ring-R step walks the tree at once when at least that many of its
+    lanes need it (1: always, as soon as one lane does — partial waves of walkers beside lanes that are shaded; 65:
+    never, every tree ray is parked first).  Same image as the oracle either way, with tiny walk budgets so that rays
+    leave the in-place walk unfinished and are parked with their stacks."""
+    from metalpathtracer_amd import capi
+    monkeypatch.setenv("MPT_OT_INPLACE", inplace)
+    monkeypatch.setenv("MPT_OT_BUDGETS", "2")
+    ctx = capi.Context(0)
+    try:
+        W, H, spp, depth = 136, 77, 3, 12
+        buf, uo = setup(ctx, name, W, H)
+        ref, _ = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, accumulate=1, sample_count=spp,
+                           seed=(4, 4), threads=8)
+        ctx.clear_sum()
+        ctx.reset_stats()
+        ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, seed=(4, 4), pipeline=capi.PIPE_ORDERED)
+        _same(ctx.read_sum(), ref)
+        st = ctx.stats()
+        assert st["tree_parked"] > 0
+    finally:
+        ctx.close()
