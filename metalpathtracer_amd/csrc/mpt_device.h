@@ -101,10 +101,11 @@ typedef const __attribute__((address_space(3))) v4f* LdsNodes;
 // ---- scene on the device ----------------------------------------------------------------------------
 // Threaded BVH node, 32 bytes (same size as the reference's, SURVEY App. D buf 0):
 //   n0 = (bmin.xyz, A)   n1 = (bmax.xyz, B)
-//   internal (B >= 0): box hit -> go to A (first child in the reference's visit order: the RIGHT child,
-//                       PathTracing.h:191-193), box miss -> go to B (skip the subtree)
-//   leaf     (B <  0): -(B+1) = first*16 + (count-1); after the leaf (hit or miss) go to A
-//   index >= n_nodes terminates.  Nodes are stored breadth-first so that the first n_lds nodes (top
+//   internal: box hit -> go to A (first child in the reference's visit order: the RIGHT child,
+//             PathTracing.h:191-193), box miss -> go to B (skip the subtree)
+//   leaf:     A = MPT_NODE_HOLD | first*16 + (count-1) — "hold this leaf": a lane's node word then names the primitives
+//             to test — and B = the node after the leaf (hit or miss)
+//   n_nodes <= index < MPT_NODE_HOLD terminates.  Nodes are stored breadth-first so that the first n_lds nodes (top
 //   of the tree) can be staged in LDS.
 // Device primitive, 48 bytes, stored in leaf order:
 //   triangle: (v0.xyz, bits(leaf << 1 | 1)) (e1.xyz, bits(mat)) (e2.xyz, bits(orig id))     e1 = v1-v0, e2 = v2-v0
