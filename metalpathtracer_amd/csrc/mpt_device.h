@@ -55,6 +55,11 @@ __device__ __forceinline__ float pcg_float(uint32_t s) { return (float)pcg_hash(
 struct U4 {
     uint32_t x, y, z, w;
 };
+// UNIFORM_KEY: the key is the same in all lanes (the render's seed).  The compiler then works out the ten round keys
+// once per kernel and keeps all twenty words in scalar registers — which the persistent kernels do not have: they were
+// spilled to VGPR lanes, and every Philox call paid 20 v_readlane + 20 hazard s_nop for them.  An empty asm after each
+// bump makes the key opaque, so that it is bumped on the scalar unit each round (2 s_add) and lives in two registers.
+template <bool UNIFORM_KEY = false>
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                             uint32_t k1) {
 #pragma unroll
@@ -68,6 +73,7 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
+        if (UNIFORM_KEY) asm volatile("" : "+s"(k0), "+s"(k1));
     }
     return U4{c0, c1, c2, c3};
 }
@@ -434,7 +440,7 @@ __device__ __forceinline__ F3 random_unit_vector(const ShadeParams& sp, const Pa
         c = cosf(t);
         u_extra = u;
     } else {
-        U4 r = philox4x32_10(g.pixel, g.sample, bounce, 0u, sp.seed_lo, sp.seed_hi);
+        U4 r = philox4x32_10<true>(g.pixel, g.sample, bounce, 0u, sp.seed_lo, sp.seed_hi);
         z = 2.0f * u01(r.x) - 1.0f;
         sincos_2pi(u01(r.y), s, c);
         u_extra = u01(r.z);

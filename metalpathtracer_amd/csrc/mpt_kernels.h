@@ -155,7 +155,7 @@ __device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, u
         seed = pcg_hash(seed);
         g.lit_seed = seed;
     } else {
-        U4 r = philox4x32_10(g.pixel, sample, 0xFFFFFFFFu, 0u, pp.sp.seed_lo, pp.sp.seed_hi);
+        U4 r = philox4x32_10<true>(g.pixel, sample, 0xFFFFFFFFu, 0u, pp.sp.seed_lo, pp.sp.seed_hi);
         xOff = (u01(r.x) - 0.5f) / pp.W;
         yOff = (u01(r.y) - 0.5f) / pp.H;
         g.lit_seed = 0;
