@@ -135,7 +135,10 @@ struct mpt_ctx {
     bool time_kernels = true;
     WaveBudgets budgets = default_budgets();  // box-test loop trips per step of ring 0..3 (measured best
                                                         // ladder; an unlimited ring-3 budget leaves ring 4 unused)
-    uint32_t wl_min = 64, wl_div = 16;  // guided path-id claims: max(wl_min, remaining / (wl_div * waves))
+    // guided path-id claims: max(wl_min, remaining / (wl_div * waves)).  wl_div, measured again after the kernels got faster
+    // (serial 256-spp render of scene.xml, two runs): 16 -> 23.4-23.8 ms, 24 22.5, 32 22.3-22.4, 48 22.3-22.5, 64 22.3-22.4,
+    // 128 22.5, 256 22.8; glass.xml, bunny x20, 32-spp and 640x360 renders move by +-1 % between 16 and 64
+    uint32_t wl_min = 64, wl_div = 32;
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
     size_t lds_budget = 78 * 1024;  // per workgroup; two workgroups per CU share the 160 KiB
