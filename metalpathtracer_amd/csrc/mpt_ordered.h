@@ -54,8 +54,10 @@
 #define MPT_OT_RINGS (2u + MPT_OT_MLEVELS) // R fresh rays, E reference-order walk, M0.. rays walking the tree
 #define MPT_OT_PARK 8u                    // stack entries a parked ray takes along (>= the LDS stack depth)
 #ifndef MPT_OT_EARLY
-#define MPT_OT_EARLY 4u                   // the node loop pauses when fewer than 1/EARLY of the lanes that entered it still search
-#endif                                    // (bunny x20: 1/2 79.3 ms, 1/3 77.9, 1/4 77.9, 1/8 79.5, 1/16 83.8)
+#define MPT_OT_EARLY 2u                   // the node loop pauses when fewer than 1/EARLY of the lanes that entered it still search
+#endif                                    // (bunny x20 at 4 waves/SIMD: 1/2 79.3 ms, 1/3 77.9, 1/4 77.9, 1/8 79.5, 1/16 83.8;
+                                          //  at 5 waves/SIMD: 1/2 64.7, 2/3 66.3, 3/4 68.0, 1/4 65.7, 1/8 69.7)
+#define MPT_OT_EARLY_NUM 1u
 
 // Diagnostics build (-DMPT_OT_TIMES): shader-clock cycles per region of k_ordered, summed over all waves, plus step and
 // lane counts per step kind (tools/gpu_ot_times.py).  Not compiled into the product library.
@@ -324,7 +326,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
         const uint32_t n_entered = (uint32_t)__popcll(__ballot(cur < MPT_OT_LEAF && (!BUDGETED || trips < budget)));
         while (cur < MPT_OT_LEAF && (!BUDGETED || trips < budget)) {
             // few lanes still searching, the others hold a leaf: test the leaves now, the search resumes afterwards
-            if ((uint32_t)__popcll(__ballot(true)) * MPT_OT_EARLY < n_entered) break;
+            if ((uint32_t)__popcll(__ballot(true)) * MPT_OT_EARLY < n_entered * MPT_OT_EARLY_NUM) break;
             // (taking ONE source per trip for the whole wave — LDS only when every searching lane is at a staged node —
             // instead of a per-lane choice was measured on bunny x20: no difference, 20.7 ms either way)
             const OtNode nd = ot_load_node<ALL_LDS>(ac, lds, cur);
