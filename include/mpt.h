@@ -69,10 +69,10 @@ enum { MPT_PIPE_WAVEFRONT = 0,  /* global SoA ray queues + wave64 ballot compact
                                    first, with the reference-order walk for the rays whose answer could depend on the
                                    order (same image bit for bit; falls back to pipeline 2 when a scene's child boxes
                                    are not nested in their parents' or it has more than 16 spheres)                  */
-       MPT_PIPE_AUTO = 4 };     /* pipeline 3 for scenes of MPT_AUTO_ORDERED_PRIMS (16384) primitives or more — where it
+       MPT_PIPE_AUTO = 4 };     /* pipeline 3 for scenes of MPT_AUTO_ORDERED_PRIMS (8192) primitives or more — where it
                                    is 1.2-1.7x faster — and pipeline 2 below that, where the two are level (scene.xml:
                                    27.1 ms either way, pipeline 2 overlaps consecutive renders slightly better)        */
-#define MPT_AUTO_ORDERED_PRIMS 16384u
+#define MPT_AUTO_ORDERED_PRIMS 8192u
 
 typedef struct mpt_render_params {
     int32_t rng_mode;        /* MPT_RNG_*                                                             */

@@ -15,7 +15,7 @@ RNG_LITERAL, RNG_PHILOX = 0, 1
 BSDF_LAMBERT, BSDF_SCATTER = 0, 1
 PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL, PIPE_ORDERED, PIPE_AUTO = 0, 1, 2, 3, 4
 REFERENCE_ORDER_PIPELINES = (PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL)  # walk the BVH in the reference's own order
-DEFAULT_PIPELINE = PIPE_AUTO  # closest-first for big scenes, reference-order wave-local below 16384 primitives
+DEFAULT_PIPELINE = PIPE_AUTO  # closest-first for big scenes, reference-order wave-local below 8192 primitives
 FLAG_COUNT_WORK = 1
 
 STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT_ERR_HIP",

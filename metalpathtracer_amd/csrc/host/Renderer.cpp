@@ -83,10 +83,10 @@ void Renderer::updateVisibleScene() {
     std::printf("Scene loaded: %zu total primitives (%zu spheres, %zu triangles)\n", scene_->getPrimitiveCount(),
                 scene_->getPrimitiveCount() - scene_->getTriangleCount(), scene_->getTriangleCount());
     // The tree is picked by primitive count: the reference's own sweep builder (R/Scene/Scene.h:195-317, the very same
-    // tree) for small scenes; from 16384 primitives the 16-bin SAH builder — 3 primitives per leaf instead of 5.6, which
+    // tree) for small scenes; from MPT_AUTO_ORDERED_PRIMS (8192) primitives the 16-bin SAH builder — 3 primitives per leaf instead of 5.6, which
     // the closest-first pipeline that MPT_PIPE_AUTO selects there turns into 1.4x the rays per second, and 3-30x less
     // build time.  MPT_BVH_MODE = reference | binned | gpu overrides (gpu = mpt_build_bvh, the linear BVH built on the device).
-    Scene::BuildMode mode = scene_->getPrimitiveCount() >= 16384 ? Scene::BuildMode::BinnedCentroid : Scene::BuildMode::ReferenceSweep;
+    Scene::BuildMode mode = scene_->getPrimitiveCount() >= MPT_AUTO_ORDERED_PRIMS ? Scene::BuildMode::BinnedCentroid : Scene::BuildMode::ReferenceSweep;
     if (const char* e = std::getenv("MPT_BVH_MODE")) {
         if (std::strcmp(e, "reference") == 0) mode = Scene::BuildMode::ReferenceSweep;
         else if (std::strcmp(e, "binned") == 0) mode = Scene::BuildMode::BinnedCentroid;
