@@ -173,7 +173,7 @@ def main():
     pipe = {"default": capi.DEFAULT_PIPELINE, "wavefront": capi.PIPE_WAVEFRONT, "megakernel": capi.PIPE_MEGAKERNEL,
             "wavelocal": capi.PIPE_WAVELOCAL, "ordered": capi.PIPE_ORDERED}[args.pipeline]
     if pipe == capi.PIPE_AUTO:   # what mpt_render resolves AUTO to (include/mpt.h), so that the line names the kernel that ran
-        pipe = capi.PIPE_ORDERED if P >= 8192 and ctx.accel_info()["ordered_ok"] else capi.PIPE_WAVELOCAL
+        pipe = ctx.accel_info()["auto_pipeline"]
     kw = dict(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_LAMBERT, max_depth=args.depth, pipeline=pipe, seed=(1, 0),
               shard_rank=rank, shard_count=world, slots_per_iter=args.slots)
 

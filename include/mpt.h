@@ -70,8 +70,9 @@ enum { MPT_PIPE_WAVEFRONT = 0,  /* global SoA ray queues + wave64 ballot compact
                                    order (same image bit for bit; falls back to pipeline 2 when a scene's child boxes
                                    are not nested in their parents' or it has more than 16 spheres)                  */
        MPT_PIPE_AUTO = 4 };     /* pipeline 3 for scenes of MPT_AUTO_ORDERED_PRIMS (8192) primitives or more — where it
-                                   is 1.2-1.7x faster — and pipeline 2 below that, where the two are level (scene.xml:
-                                   27.1 ms either way, pipeline 2 overlaps consecutive renders slightly better)        */
+                                   is 1.5-2.2x faster — and pipeline 2 below that (scene.xml: pipeline 2 leads by a few
+                                   per cent since its box-test loop was rewritten for the scalar unit).  mpt_accel_info
+                                   out[7] tells which of the two AUTO stands for with the uploaded scene.               */
 #define MPT_AUTO_ORDERED_PRIMS 8192u
 
 typedef struct mpt_render_params {
@@ -187,7 +188,8 @@ int mpt_trace_rays_ordered(mpt_ctx* ctx, const float* origins, const float* dire
 
 /* Shape of the product's own acceleration structure for the uploaded scene: out[0] = 1 if MPT_PIPE_ORDERED can be used,
  * [1] own 4-wide nodes, [2] its depth, [3] nodes staged in LDS, [4] spheres on the always list, [5] reference leaves,
- * [6] primitives staged in LDS, [7] reserved.                                                                          */
+ * [6] primitives staged in LDS, [7] the pipeline MPT_PIPE_AUTO resolves to for this scene (MPT_PIPE_WAVELOCAL or
+ * MPT_PIPE_ORDERED).                                                                                                   */
 int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 
 /* BVH construction on the GPU — stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,

@@ -337,7 +337,7 @@ class Context:
     def accel_info(self):
         out = (C.c_uint64 * 8)()
         self._chk(self.L.mpt_accel_info(self.h, out), "mpt_accel_info")
-        keys = ("ordered_ok", "nodes", "depth", "lds_nodes", "always_spheres", "reference_leaves", "lds_prims")
+        keys = ("ordered_ok", "nodes", "depth", "lds_nodes", "always_spheres", "reference_leaves", "lds_prims", "auto_pipeline")
         return dict(zip(keys, [int(v) for v in out]))
 
     def kat_pcg(self, seeds):

@@ -29,8 +29,8 @@ float Renderer::hostRandomFloat() {
     return static_cast<float>(hostSeed_) / static_cast<float>(std::numeric_limits<uint32_t>::max());
 }
 
-Renderer::Renderer(int deviceOrdinal, const std::string& scenePath, const std::string& assetRoot)
-    : device_(deviceOrdinal), scene_(new Scene()), scenePath_(scenePath), assetRoot_(assetRoot) {
+Renderer::Renderer(int deviceOrdinal, const std::string& scenePath, const std::string& assetRoot, int buildMode)
+    : device_(deviceOrdinal), scene_(new Scene()), scenePath_(scenePath), assetRoot_(assetRoot), buildMode_(buildMode) {
     std::memset(&uniforms_, 0, sizeof uniforms_);
     std::memset(&params_, 0, sizeof params_);
     params_.rng_mode = MPT_RNG_LITERAL;  // what the reference's shader does
@@ -82,16 +82,24 @@ void Renderer::updateVisibleScene() {
     std::fputs(log.c_str(), stdout);
     std::printf("Scene loaded: %zu total primitives (%zu spheres, %zu triangles)\n", scene_->getPrimitiveCount(),
                 scene_->getPrimitiveCount() - scene_->getTriangleCount(), scene_->getTriangleCount());
-    // The tree is picked by primitive count: the reference's own sweep builder (R/Scene/Scene.h:195-317, the very same
-    // tree) for small scenes; from MPT_AUTO_ORDERED_PRIMS (8192) primitives the 16-bin SAH builder — 3 primitives per leaf instead of 5.6, which
-    // the closest-first pipeline that MPT_PIPE_AUTO selects there turns into 1.4x the rays per second, and 3-30x less
-    // build time.  MPT_BVH_MODE = reference | binned | gpu overrides (gpu = mpt_build_bvh, the linear BVH built on the device).
-    Scene::BuildMode mode = scene_->getPrimitiveCount() >= MPT_AUTO_ORDERED_PRIMS ? Scene::BuildMode::BinnedCentroid : Scene::BuildMode::ReferenceSweep;
+    // The drop-in default is the reference's own sweep builder (R/Scene/Scene.h:195-317, the very same tree): with the
+    // literal RNG and the frame protocol the reference's answer on ties and inconsistent hits depends on the visit order,
+    // so the tree is part of the behaviour.  A caller that wants throughput asks for it (setBuildMode / MPT_BVH_MODE):
+    // "auto" = from MPT_AUTO_ORDERED_PRIMS (8192) primitives the 16-bin SAH builder — 3 primitives per leaf instead of
+    // 5.6, which the closest-first pipeline that MPT_PIPE_AUTO selects there turns into 1.4x the rays per second, at 3-30x
+    // less build time; "gpu" = mpt_build_bvh, the linear BVH built on the device.
+    int want = buildMode_;
     if (const char* e = std::getenv("MPT_BVH_MODE")) {
-        if (std::strcmp(e, "reference") == 0) mode = Scene::BuildMode::ReferenceSweep;
-        else if (std::strcmp(e, "binned") == 0) mode = Scene::BuildMode::BinnedCentroid;
-        else if (std::strcmp(e, "gpu") == 0) mode = Scene::BuildMode::GpuLbvh;
+        if (std::strcmp(e, "reference") == 0) want = BUILD_REFERENCE;
+        else if (std::strcmp(e, "binned") == 0) want = BUILD_BINNED;
+        else if (std::strcmp(e, "gpu") == 0) want = BUILD_GPU;
+        else if (std::strcmp(e, "auto") == 0) want = BUILD_AUTO;
     }
+    if (want == BUILD_AUTO) want = scene_->getPrimitiveCount() >= MPT_AUTO_ORDERED_PRIMS ? BUILD_BINNED : BUILD_REFERENCE;
+    const Scene::BuildMode mode = want == BUILD_BINNED ? Scene::BuildMode::BinnedCentroid
+                                  : want == BUILD_GPU  ? Scene::BuildMode::GpuLbvh
+                                                       : Scene::BuildMode::ReferenceSweep;
+    std::printf("BVH builder: %s\n", want == BUILD_BINNED ? "binned SAH (host)" : want == BUILD_GPU ? "linear BVH (device)" : "reference sweep SAH");
     scene_->buildBVH(mode);
     std::printf("BVH node count: %zu\n", scene_->getBVHNodeCount());
     buildBuffers();

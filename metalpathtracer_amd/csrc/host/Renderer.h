@@ -26,8 +26,10 @@ struct DrawableSize {
 
 class Renderer {
 public:
+    // tree builder used by updateVisibleScene: the reference's own (the drop-in default), or one of the product's
+    enum { BUILD_REFERENCE = 0, BUILD_BINNED = 1, BUILD_GPU = 2, BUILD_AUTO = 3 };
     explicit Renderer(int deviceOrdinal = 0, const std::string& scenePath = std::string(),
-                      const std::string& assetRoot = std::string());
+                      const std::string& assetRoot = std::string(), int buildMode = BUILD_REFERENCE);
     ~Renderer();
     Renderer(const Renderer&) = delete;
     Renderer& operator=(const Renderer&) = delete;
@@ -45,6 +47,7 @@ public:
     // ---- extensions (not in the reference) ----
     void setScenePath(const std::string& xml, const std::string& assetRoot = std::string());
     void setRenderParams(const mpt_render_params& p) { params_ = p; }
+    void setBuildMode(int mode) { buildMode_ = mode; }   // takes effect at the next updateVisibleScene()
     mpt_render_params& renderParams() { return params_; }
     Scene* scene() { return scene_; }
     mpt_ctx* context() { return ctx_; }
@@ -67,6 +70,7 @@ private:
     mpt_render_params params_;
     uint32_t hostSeed_ = 92407235u;  // R/Renderer/Renderer.cpp:32
     bool sceneUploaded_ = false;
+    int buildMode_ = BUILD_REFERENCE;
 };
 
 }  // namespace MetalCppPathTracer

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -22,7 +23,9 @@ static void usage() {
         "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter]\n"
         "           [--pipeline auto|ordered|wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
         "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
-        "           [--gpus N] [--camera-path FILE [--out-dir runs]]\n"
+        "           [--gpus N] [--camera-path FILE [--out-dir runs]] [--bvh reference|binned|gpu|auto]\n"
+        "  --bvh             tree builder: the reference's sweep SAH (default with --rng literal, --frames and --camera-path:\n"
+        "                    the drop-in behaviour) or auto (default for batch renders: binned SAH from 8192 primitives)\n"
         "  --frames N        run the reference's frame protocol (N draw() calls, running mean) instead of batch spp\n"
         "  --gpus N          batch mode on GPUs device .. device+N-1: 8x8 pixel tiles interleaved over the GPUs, one RCCL\n"
         "                    reduce(sum) of the HDR framebuffer onto the first (mpt_comm_create_all / mpt_reduce_sum)\n"
@@ -86,8 +89,9 @@ static int playCameraPath(Renderer& r, OffscreenView& view, const std::string& p
         std::fprintf(stderr, "cannot open camera path %s\n", path.c_str());
         return -1;
     }
-    std::string cmd = "mkdir -p '" + outDir + "'";
-    if (std::system(cmd.c_str()) != 0) std::fprintf(stderr, "cannot create %s\n", outDir.c_str());
+    std::error_code ec;
+    std::filesystem::create_directories(outDir, ec);
+    if (ec) std::fprintf(stderr, "cannot create %s: %s\n", outDir.c_str(), ec.message().c_str());
     char buf[512];
     int frame = 0;
     while (std::fgets(buf, sizeof buf, f)) {
@@ -122,12 +126,12 @@ static int playCameraPath(Renderer& r, OffscreenView& view, const std::string& p
 // Batch render on N GPUs driven by this one host thread (SURVEY.md 8e / include/mpt.h "multi-GPU"): every GPU gets the
 // scene, renders its interleaved tile shard asynchronously, and ONE ncclReduce(sum) lands the HDR sum on the first GPU.
 static int renderOnSeveralGpus(const std::string& scene, const std::string& assetRoot, const std::string& out, int width, int height,
-                               int spp, int device, int gpus, mpt_render_params prm, const float* camPos, const float* camDir,
+                               int spp, int device, int gpus, int bvh, mpt_render_params prm, const float* camPos, const float* camDir,
                                const float* camUp, float vfov) {
     std::vector<std::unique_ptr<Renderer>> rs;
     mpt_comm* comm = nullptr;
     try {
-        for (int g = 0; g < gpus; ++g) rs.emplace_back(new Renderer(device + g, scene, assetRoot));
+        for (int g = 0; g < gpus; ++g) rs.emplace_back(new Renderer(device + g, scene, assetRoot, bvh));
         if (camPos) Camera::position = mpt::float3(camPos[0], camPos[1], camPos[2]);
         if (camDir) Camera::forward = mpt::normalize(mpt::float3(camDir[0], camDir[1], camDir[2]));
         if (camUp) Camera::up = mpt::normalize(mpt::float3(camUp[0], camUp[1], camUp[2]));
@@ -184,6 +188,7 @@ static int renderOnSeveralGpus(const std::string& scene, const std::string& asse
 int main(int argc, char** argv) {
     std::string scene, assetRoot, out, cameraPath, outDir = "runs";
     int width = 1280, height = 720, spp = 64, depth = 32, device = 0, frames = 0, gpus = 1;
+    int bvh = -1;   // -1 = by mode: the reference's builder for the frame protocol / the literal RNG, auto for batch renders
     unsigned seed = 1;
     float camPos[3], camDir[3], camUp[3], vfov = 0.0f;
     bool havePos = false, haveDir = false, haveUp = false;
@@ -214,6 +219,12 @@ int main(int argc, char** argv) {
         else if (a == "--camera-path") cameraPath = next();
         else if (a == "--out-dir") outDir = next();
         else if (a == "--out") out = next();
+        else if (a == "--bvh") {
+            const char* v = next();
+            bvh = std::strcmp(v, "reference") == 0 ? Renderer::BUILD_REFERENCE
+                  : std::strcmp(v, "binned") == 0  ? Renderer::BUILD_BINNED
+                  : std::strcmp(v, "gpu") == 0     ? Renderer::BUILD_GPU : Renderer::BUILD_AUTO;
+        }
         else if (a == "--camera-pos" || a == "--camera-dir" || a == "--camera-up") {
             float v[3] = {0, 0, 0};
             if (std::sscanf(next(), "%f,%f,%f", &v[0], &v[1], &v[2]) != 3) {
@@ -245,10 +256,11 @@ int main(int argc, char** argv) {
     }
     prm.max_depth = depth;
     prm.seed_lo = seed;
-    if (gpus > 1) return renderOnSeveralGpus(scene, assetRoot, out, width, height, spp, device, gpus, prm, havePos ? camPos : nullptr,
+    if (bvh < 0) bvh = prm.rng_mode == MPT_RNG_LITERAL || frames > 0 || !cameraPath.empty() ? Renderer::BUILD_REFERENCE : Renderer::BUILD_AUTO;
+    if (gpus > 1) return renderOnSeveralGpus(scene, assetRoot, out, width, height, spp, device, gpus, bvh, prm, havePos ? camPos : nullptr,
                                              haveDir ? camDir : nullptr, haveUp ? camUp : nullptr, vfov);
     try {
-        Renderer r(device, scene, assetRoot);
+        Renderer r(device, scene, assetRoot, bvh);
         r.setRenderParams(prm);
         // the reference hard-codes Camera::reset(); the flags overwrite the same globals before the viewport is built
         if (havePos) Camera::position = mpt::float3(camPos[0], camPos[1], camPos[2]);

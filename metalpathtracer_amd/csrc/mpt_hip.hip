@@ -982,6 +982,14 @@ static inline uint64_t pass_path_limit(int pipeline) {
 
 static inline bool count_flag(const mpt_render_params* p) { return (p->flags & MPT_FLAG_COUNT_WORK) != 0; }
 
+// the closest-first pipeline needs nested boxes and few spheres (mpt_upload_scene); otherwise the reference-order
+// wave-local pipeline renders the same image
+static int resolve_pipeline(const mpt_ctx* ctx, int pipeline) {
+    if (pipeline == MPT_PIPE_AUTO) pipeline = ctx->n_prims >= MPT_AUTO_ORDERED_PRIMS ? MPT_PIPE_ORDERED : MPT_PIPE_WAVELOCAL;
+    if (pipeline == MPT_PIPE_ORDERED && !ctx->acc_ok) pipeline = MPT_PIPE_WAVELOCAL;
+    return pipeline;
+}
+
 // Runs one pass of S samples/pixel over this rank's tiles; leaves the per-path results in d_slots.
 static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t sample_begin, uint32_t S, PassParams& pp,
                     uint32_t& n_local_tiles, bool time_kernels) {
@@ -1001,11 +1009,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     if (rc) return rc;
     if (p->rng_mode == MPT_RNG_LITERAL && (rc = ensure_pixel_seeds(ctx))) return rc;
 
-    // the closest-first pipeline needs nested boxes and few spheres (mpt_upload_scene); otherwise the reference-order
-    // wave-local pipeline renders the same image
-    int pipeline = p->pipeline;
-    if (pipeline == MPT_PIPE_AUTO) pipeline = ctx->n_prims >= MPT_AUTO_ORDERED_PRIMS ? MPT_PIPE_ORDERED : MPT_PIPE_WAVELOCAL;
-    if (pipeline == MPT_PIPE_ORDERED && !ctx->acc_ok) pipeline = MPT_PIPE_WAVELOCAL;
+    const int pipeline = resolve_pipeline(ctx, p->pipeline);
     pp.scene = scene_dev(ctx);
     pp.q[0] = L.q[0];
     pp.q[1] = L.q[1];
@@ -1284,6 +1288,9 @@ static int render_async_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     // a render that fails half way: drain what it has enqueued, forget its event pairs and give the lane back, so that
     // the next render starts from a clean lane (the HDR sum may hold some of this render's passes: the caller clears it)
     auto abandon = [&](int code) {
+        // (the statistics copy that normally clears them never runs for an abandoned render)
+        hipMemsetAsync(&L.d_desc->paths, 0, MPT_DESC_COUNTERS * sizeof(unsigned long long), L.stream);
+        hipMemsetAsync(&L.d_desc->overflow, 0, 4, L.stream);
         hipStreamSynchronize(L.stream);
         L.pending_timed.clear();
         L.ev_used = 0;
@@ -1560,7 +1567,8 @@ extern "C" int mpt_trace_rays_ordered(mpt_ctx* ctx, const float* o, const float*
 extern "C" int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]) {
     if (!ctx || !out) return MPT_ERR_INVALID_ARG;
     if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
-    const uint64_t v[8] = {ctx->acc_ok ? 1u : 0u, ctx->n_acc_nodes, ctx->acc_depth, ctx->ot_lds_nodes, ctx->n_always, ctx->n_ref_leaves, ctx->ot_lds_prims, 0};
+    const uint64_t v[8] = {ctx->acc_ok ? 1u : 0u, ctx->n_acc_nodes, ctx->acc_depth, ctx->ot_lds_nodes, ctx->n_always, ctx->n_ref_leaves, ctx->ot_lds_prims,
+                           (uint64_t)resolve_pipeline(ctx, MPT_PIPE_AUTO)};
     memcpy(out, v, sizeof v);
     return MPT_OK;
 }
@@ -1604,6 +1612,7 @@ struct RcclApi {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -1628,6 +1637,7 @@ static const char* rccl_load() {  // nullptr = ok, else what failed
     MPT_SYM(CommInitAll, "ncclCommInitAll")
     MPT_SYM(CommInitRank, "ncclCommInitRank")
     MPT_SYM(CommDestroy, "ncclCommDestroy")
+    MPT_SYM(CommAbort, "ncclCommAbort")
     MPT_SYM(Reduce, "ncclReduce")
     MPT_SYM(GroupStart, "ncclGroupStart")
     MPT_SYM(GroupEnd, "ncclGroupEnd")
@@ -1643,6 +1653,7 @@ struct mpt_comm {
     std::vector<mpt_ctx*> ctxs;      // local contexts (all N in one process, or this rank's one)
     std::vector<ncclComm_t> comms;   // one per local context; empty when nranks == 1
     int nranks = 1, first_rank = 0;  // global size; global rank of ctxs[0]
+    bool aborted = false;            // a local failure aborted the communicators: nothing more can be reduced
     std::string err;
 };
 
@@ -1707,37 +1718,63 @@ extern "C" int mpt_comm_create_rank(mpt_ctx* ctx, int rank, int nranks, const vo
     }
 }
 
+// A rank that cannot enter the collective must not leave its peers waiting in it: the local communicators are aborted
+// (ncclCommAbort), which makes the peers' ncclReduce fail instead of hanging on their GPUs.  The job is over then — the
+// communicator cannot be used again (mpt_reduce_sum returns MPT_ERR_NOT_READY on it), the caller tears down and restarts.
+static void comm_abort(mpt_comm* c) {
+    for (ncclComm_t& k : c->comms) {
+        if (k && g_rccl.CommAbort) g_rccl.CommAbort(k);
+        k = nullptr;
+    }
+    c->aborted = true;
+}
+
 extern "C" int mpt_reduce_sum(mpt_comm* c, int root) {
     if (!c || root < 0 || root >= c->nranks) return MPT_ERR_INVALID_ARG;
+    if (c->aborted) {
+        c->err = "communicator was aborted by an earlier failure";
+        return MPT_ERR_NOT_READY;
+    }
     // every local context: collect the renders in flight (their resolves have then updated the HDR sum)
+    int local_rc = MPT_OK;
     for (mpt_ctx* ctx : c->ctxs) {
         int rc = wait_impl(ctx);
         if (rc) {
             c->err = ctx->err;
-            return rc;
+            local_rc = rc;
+            break;
         }
         if (!ctx->d_sum || ctx->W != c->ctxs[0]->W || ctx->H != c->ctxs[0]->H) {
             c->err = "contexts of a communicator must be sized alike (mpt_resize)";
-            return MPT_ERR_NOT_READY;
+            local_rc = MPT_ERR_NOT_READY;
+            break;
         }
+    }
+    if (local_rc) {
+        if (c->nranks > 1) comm_abort(c);
+        return local_rc;
     }
     if (c->nranks == 1) return MPT_OK;  // one GPU holds the whole image already
     const size_t count = (size_t)c->ctxs[0]->W * c->ctxs[0]->H * 4;
     ncclResult_t r = g_rccl.GroupStart();
-    for (size_t i = 0; i < c->ctxs.size() && r == ncclSuccess; ++i) {
-        mpt_ctx* ctx = c->ctxs[i];
-        if (hipSetDevice(ctx->device) != hipSuccess) r = ncclUnhandledCudaError;
-        else r = g_rccl.Reduce(ctx->d_sum, ctx->d_sum, count, ncclFloat32, ncclSum, root, c->comms[i], ctx->stream);
+    if (r == ncclSuccess) {   // (GroupEnd always follows a successful GroupStart)
+        for (size_t i = 0; i < c->ctxs.size() && r == ncclSuccess; ++i) {
+            mpt_ctx* ctx = c->ctxs[i];
+            if (hipSetDevice(ctx->device) != hipSuccess) r = ncclUnhandledCudaError;
+            else r = g_rccl.Reduce(ctx->d_sum, ctx->d_sum, count, ncclFloat32, ncclSum, root, c->comms[i], ctx->stream);
+        }
+        ncclResult_t e = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = e;
     }
-    ncclResult_t e = g_rccl.GroupEnd();
-    if (r == ncclSuccess) r = e;
     if (r != ncclSuccess) {
         c->err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r);
+        comm_abort(c);
         return MPT_ERR_HIP;
     }
     for (mpt_ctx* ctx : c->ctxs) {
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
             c->err = "stream synchronisation after ncclReduce failed";
+            comm_abort(c);
             return MPT_ERR_HIP;
         }
     }

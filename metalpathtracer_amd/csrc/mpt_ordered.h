@@ -108,23 +108,18 @@ typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2u* LdsStack;
 
 // Per-lane stack in LDS: entry e of a lane at lds[e * 64] (entry-major: the 64 lanes of a wave hit 64 different bank
-// pairs whatever their depths).  entry = (entry-distance key, child reference).  When the stack is full the FARTHEST
-// of the children being pushed is dropped and the walk is marked incomplete: the caller walks the tree once more from
-// the root with the best t found so far — nearly everything is culled then, so that second pass is short (1.5e-5 of the
-// rays on scene.xml, 0.7 % on bunny x20 with 8 entries).
+// pairs whatever their depths).  entry = (entry-distance key, child reference).  When a node's children do not all fit,
+// the FARTHEST of them are the ones dropped (ot_push_sorted) and the walk is marked incomplete: the caller walks the tree
+// once more from the root with the best t found so far — nearly everything is culled then, so that second pass is
+// short (1.5e-5 of the rays on scene.xml, 0.7 % on bunny x20 with 8 entries).
 struct OtStack {
     LdsStack lds;
     uint32_t depth;
 };
-__device__ __forceinline__ void ot_push(const OtStack& st, uint32_t& sp, uint32_t key, uint32_t ref, bool& lost) {
-    if (sp < st.depth) {
-        st.lds[sp * 64u] = v2u{key, ref};
-        ++sp;
-    } else {
-        lost = true;
-    }
-}
-
+// k1 <= k2 <= k3: the keys of a node's children behind the nearest one (KEY_MISS = not hit; hits come first).  Pushed
+// farthest first, so that the nearest is popped first; with `room` free entries only the nearest `room` of them go in.
+__device__ __forceinline__ void ot_push_sorted(const OtStack& st, uint32_t& sp, const uint4& ref, uint32_t k1, uint32_t k2,
+                                               uint32_t k3, bool& lost);
 struct OtRay {
     float idx, idy, idz, ox, oy, oz;  // approximate 1/d and o/d: own boxes are padded for it (mpt_hip.hip)
 };
@@ -290,6 +285,15 @@ __device__ __forceinline__ uint32_t ot_pick(const uint4& ref, uint32_t key) {  /
     const uint32_t a = odd ? ref.y : ref.x, b = odd ? ref.w : ref.z;
     return high ? b : a;
 }
+__device__ __forceinline__ void ot_push_sorted(const OtStack& st, uint32_t& sp, const uint4& ref, uint32_t k1, uint32_t k2,
+                                               uint32_t k3, bool& lost) {
+    const uint32_t room = st.depth - sp;
+    const bool h1 = k1 < MPT_OT_KEY_MISS, h2 = k2 < MPT_OT_KEY_MISS, h3 = k3 < MPT_OT_KEY_MISS;
+    if (h3 && room >= 3u) st.lds[sp++ * 64u] = v2u{k3, ot_pick(ref, k3)};
+    if (h2 && room >= 2u) st.lds[sp++ * 64u] = v2u{k2, ot_pick(ref, k2)};
+    if (h1 && room >= 1u) st.lds[sp++ * 64u] = v2u{k1, ot_pick(ref, k1)};
+    lost = lost || (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3 > room;
+}
 __device__ __forceinline__ uint32_t ot_pop_next(const OtStack& st, uint32_t& sp, float lim) {
     while (sp > 0u) {
         --sp;
@@ -351,13 +355,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             ot_sort2(k1, k2);
             if (k0 < MPT_OT_KEY_MISS) {
                 cur = ot_pick(nd.ref, k0);
-                if (k1 < MPT_OT_KEY_MISS) {  // farthest first, so that the nearest is popped first
-                    if (k2 < MPT_OT_KEY_MISS) {
-                        if (k3 < MPT_OT_KEY_MISS) ot_push(st, sp, k3, ot_pick(nd.ref, k3), overflow);
-                        ot_push(st, sp, k2, ot_pick(nd.ref, k2), overflow);
-                    }
-                    ot_push(st, sp, k1, ot_pick(nd.ref, k1), overflow);
-                }
+                if (k1 < MPT_OT_KEY_MISS) ot_push_sorted(st, sp, nd.ref, k1, k2, k3, overflow);
             } else {
                 cur = ot_pop_next(st, sp, lim);
             }

@@ -52,3 +52,40 @@ def test_no_cpu_fallback_in_product():
     for mk in ("Makefile", os.path.join("metalpathtracer_amd", "csrc", "host", "Makefile")):
         text = open(os.path.join(ROOT, mk)).read()
         assert "-lmpt_oracle" not in text
+
+
+def test_comm_argument_checks_do_not_touch_rccl():
+    """The N > 1 entry points reject bad arguments with MPT_ERR_INVALID_ARG before anything is dereferenced or librccl is
+    opened (the only part of the multi-GPU path that runs without a second GPU; the N = 1 path has a GPU test)."""
+    L = capi.load()
+    vp = C.c_void_p
+    out = vp(0x1234)
+    fake_ctx = C.create_string_buffer(64)          # never dereferenced by the checks below
+    ctxs = (vp * 2)(C.addressof(fake_ctx), None)
+    INVALID = 1
+    # mpt_comm_create_all: null output, null array, n < 1, a null context in the array
+    assert L.mpt_comm_create_all(ctxs, 1, None) == INVALID
+    assert L.mpt_comm_create_all(None, 1, C.byref(out)) == INVALID and out.value is None
+    out = vp(0x1234)
+    assert L.mpt_comm_create_all(ctxs, 0, C.byref(out)) == INVALID and out.value is None
+    out = vp(0x1234)
+    assert L.mpt_comm_create_all(ctxs, 2, C.byref(out)) == INVALID and out.value is None
+    # mpt_comm_create_rank: null context / output, nranks < 1, rank out of range, nranks > 1 without an id
+    ident = C.create_string_buffer(128)
+    for args in ((None, 0, 1, ident), (fake_ctx, 0, 0, ident), (fake_ctx, -1, 2, ident), (fake_ctx, 2, 2, ident),
+                 (fake_ctx, 0, 2, None)):
+        out = vp(0x1234)
+        assert L.mpt_comm_create_rank(args[0], args[1], args[2], args[3], C.byref(out)) == INVALID, args[1:3]
+        assert out.value is None
+    assert L.mpt_comm_create_rank(fake_ctx, 0, 1, None, None) == INVALID
+    assert L.mpt_comm_unique_id(None) == INVALID
+    # mpt_reduce_sum: null communicator, root out of range (a one-rank communicator needs no RCCL and no device)
+    assert L.mpt_reduce_sum(None, 0) == INVALID
+    comm = vp()
+    assert L.mpt_comm_create_rank(fake_ctx, 0, 1, None, C.byref(comm)) == 0 and comm.value
+    assert L.mpt_reduce_sum(comm, 1) == INVALID
+    assert L.mpt_reduce_sum(comm, -1) == INVALID
+    assert L.mpt_comm_last_error(comm) == b""
+    assert L.mpt_comm_destroy(comm) == 0
+    assert L.mpt_comm_destroy(None) == INVALID
+    assert L.mpt_comm_last_error(None) == b"null communicator"
