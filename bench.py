@@ -38,7 +38,6 @@ B_QUEUE = 168.0        # compulsory wavefront-queue bytes per ra
 PIPE_NAMES = {0: "wavefront (global SoA queues)", 1: "megakernel", 2: "wave-local wavefront, reference-order walk",
               3: "wave-local wavefront, closest-first walk of the own 4-wide BVH"}
 PIPE_KERNEL = {0: "k_step", 1: "k_megakernel", 2: "k_wavelocal", 3: "k_ordered"}
-PIPE_PROFILE = {2: "r02_pmc_wavelocal.json", 3: "r02_pmc_ordered.json"}
 
 
 def parse():
@@ -58,31 +57,47 @@ def parse():
     ap.add_argument("--slots", type=int, default=0, help="wavefront width (ray slots per iteration), 0 = default")
     ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the untimed extras (Cornell box and bunny x20 at 1920x1080 x 256 spp, one serial render each)")
     return ap.parse_args()
 
 
-def counter_profile(pipe):
+def counter_profile(kernel, workload):
     """Per-launch counters of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_round.sh on
-    tools/prof_run.py: same scene / size / spp / depth as the default bench step; PMC cannot be collected from inside
-    this process).  Returns per-ray figures, or None when no profile of this pipeline is committed."""
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", PIPE_PROFILE[pipe])))
+    tools/prof_run.py; PMC cannot be collected from inside this process).  A profile is used only if it was taken on THIS
+    workload (scene, size, spp, depth, tree builder, knobs) with THIS build (library or source sha256, capi.build_id): its
+    per-ray counters are then scaled by this run's rays per launch and HIP-event launch time.  Returns (per-ray figures or
+    None, {"profile_stale": true / "profile_missing": ..., ...}): nothing is guessed and nothing is swallowed."""
+    import glob
+    from metalpathtracer_amd import capi
+    bid = capi.build_id()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+        prof = json.load(open(f))          # (a malformed profile is an error, not a silent null)
+        wl = prof.get("workload")
+        if not wl or kernel not in prof.get("kernel", ""):
+            continue
+        if any(wl.get(k) != workload[k] for k in ("scene", "width", "height", "spp", "depth", "bvh", "env")):
+            continue
+        rel = os.path.relpath(f, ROOT)
+        if wl.get("source_sha256") != bid["source_sha256"] and wl.get("lib_sha256") != bid["lib_sha256"]:
+            stale = stale or {"profile_stale": True, "profile": rel, "profile_source_sha256": wl.get("source_sha256"),
+                              "this_source_sha256": bid["source_sha256"]}
+            continue
         c, rays, ms = prof["counters"], float(prof["rays_per_launch"]), float(prof["kernel_ms"])
-        clock_ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e-3) / 1e9
         return {
-            "file": "profiles/" + PIPE_PROFILE[pipe],
+            "file": rel, "build": {k: wl.get(k) for k in ("lib_sha256", "source_sha256")},
             "valu_per_ray": c["SQ_INSTS_VALU"] / rays, "salu_per_ray": c["SQ_INSTS_SALU"] / rays,
             "lds_per_ray": c["SQ_INSTS_LDS"] / rays,
             "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
             "hbm_bytes_per_ray": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / rays,   # gfx950: FETCH_SIZE x2
             "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
-            "clock_ghz": clock_ghz,
+            "clock_ghz": c["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e-3) / 1e9,
             "wave_cycles_split": {k: c[n] / c["SQ_WAVE_CYCLES"] for k, n in
                                   (("issuing", "SQ_ACTIVE_INST_ANY"), ("waitcnt", "SQ_WAIT_ANY"), ("issue_stall", "SQ_WAIT_INST_ANY"))},
             "profiled_kernel_ms": ms,
-        }
-    except Exception:
-        return None
+        }, {}
+    return None, stale or {"profile_missing": "no committed counter profile of %s for this workload" % kernel}
 
 
 def host_cores():
@@ -124,6 +139,41 @@ def cpu_baseline(args, scene_buffers, prim_count, tri_count):
                        % (args.width, args.height, spp, args.depth, ct["rays"], dt, cores),
                 single_core={"value": c1["rays"] / dt1 / 1e6, "unit": "Mrays/s",
                              "sample": "%d spp: %d rays in %.2f s on 1 thread" % (spp1, c1["rays"], dt1)}), (n_node, n_prim, h)
+
+
+CORNELL_CAM = dict(pos=(0.0, 1.0, 3.4), fwd=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), vfov=40.0)
+
+
+def extra_workloads(ctx, capi, host, depth):
+    """Untimed extras (N = 1), like serial_ms_per_render: ONE serial 1920x1080 x 256 spp render of north_star's "synthetic
+    Cornell-style scene" and of bunny x20 (BASELINE.json configs[2]'s scene, on the tree the Renderer picks for it), so that
+    the driver's record carries them.  HIP-event time of the whole render, best of two after a warm-up."""
+    out = []
+    for name, xml, bvh, cam in (("cornell.xml", "cornell.xml", host.BVH_REFERENCE_SWEEP, CORNELL_CAM),
+                                ("bunny20.xml", "bunny20.xml", host.BVH_BINNED_CENTROID, None)):
+        sc = host.Scene()
+        st, log = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", xml), sc)
+        if st != 0:
+            out.append({"workload": name, "error": log[-200:]})
+            continue
+        sc.buildBVH(bvh)
+        ctx.upload_scene(*sc.buffers())
+        W, H, spp = 1920, 1080, 256
+        ctx.resize(W, H)
+        ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam))
+        best = None
+        for k in range(3):
+            ctx.reset_stats()
+            ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_LAMBERT, max_depth=depth, pipeline=capi.PIPE_AUTO, seed=(1, 0),
+                       sample_begin=k * spp, sample_count=spp)
+            s = ctx.stats()
+            if k and (best is None or s["total_ms"] < best["total_ms"]):
+                best = s
+        out.append({"workload": "%s %dx%d x %d spp, depth %d, one serial render" % (name, W, H, spp, depth),
+                    "prims": sc.getPrimitiveCount(), "bvh_builder": {0: "reference", 1: "binned", 2: "gpu"}[bvh],
+                    "pipeline": PIPE_NAMES[ctx.accel_info()["auto_pipeline"]], "ms_per_render": best["total_ms"],
+                    "mrays_per_s": best["rays"] / best["total_ms"] / 1e3, "rays": best["rays"], "paths": best["paths"]})
+    return out
 
 
 def main():
@@ -262,17 +312,23 @@ def main():
             out["cpu_baseline"], (n_node, n_prim, h) = cpu_baseline(args, buffers, P, T)
         b_ray = B_QUEUE + 32.0 * n_node + 52.0 * n_prim + 32.0 * h
         out["serial_ms_per_render"] = serial_ms
+        if world == 1 and not args.no_extra_workloads:
+            out["extra_workloads"] = extra_workloads(ctx, capi, host, args.depth)
         out["config"]["serial_mrays_per_s"] = rays_local / args.steps / serial_ms / 1e3 if serial_ms else None
         if launches and kernel_ms > 0:
             rays_per_launch = rays_local / launches
             sec_per_launch = kernel_ms * 1e-3 / launches
-            prof = counter_profile(pipe)
+            workload = {"scene": os.path.basename(args.scene), "width": W, "height": H, "spp": spp, "depth": args.depth,
+                        "bvh": {"reference": 0, "binned": 1, "gpu": 2}[args.bvh], "env": capi.knob_env()}
+            prof, why = counter_profile(PIPE_KERNEL[pipe], workload)
             rf = {"kernel": PIPE_KERNEL[pipe], "launches": launches, "avg_launch_ms": kernel_ms / launches,
                   "rays_per_launch": rays_per_launch}
             if prof:
-                # vector-ALU issue: wave64 instructions per second vs 1024 SIMD-32s issuing one every 2 cycles
+                # vector-ALU issue: wave64 instructions per second vs 1024 SIMD-32s issuing one every 2 cycles at the chip's
+                # 2.4 GHz (MI355X_MICROARCH.md).  The clock the kernel actually held is lower (DVFS): that fraction is
+                # reported next to it, it is not the headline.
                 valu_rate = prof["valu_per_ray"] * rays_per_launch / sec_per_launch / 1e9            # G wave-instr/s
-                valu_peak = N_SIMD * prof["clock_ghz"] / 2.0
+                valu_peak = N_SIMD * MAX_CLOCK_GHZ / 2.0
                 hbm_bytes = prof["hbm_bytes_per_ray"] * rays_per_launch
                 hbm_rate = hbm_bytes / sec_per_launch / 1e9
                 valu_frac, hbm_frac = valu_rate / valu_peak, hbm_rate / HBM_PEAK_GBS
@@ -282,24 +338,28 @@ def main():
                     rf.update(bound="hbm", achieved=hbm_rate, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac)
                 rf["traffic"] = hbm_bytes
                 rf["valu"] = {"achieved": valu_rate, "peak": valu_peak, "unit": "G wave64-instr/s", "frac": valu_frac,
-                              "frac_at_2.4GHz": valu_rate / (N_SIMD * MAX_CLOCK_GHZ / 2.0), "instr_per_ray": prof["valu_per_ray"],
-                              "lane_utilisation": prof["lane_utilisation"],
+                              "frac_at_measured_clock": valu_rate / (N_SIMD * prof["clock_ghz"] / 2.0),
+                              "measured_clock_ghz": prof["clock_ghz"],
+                              "measured_clock_note": "GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the PROFILED launch (profiled passes "
+                                                     "clock lower than un-profiled ones)",
+                              "instr_per_ray": prof["valu_per_ray"], "lane_utilisation": prof["lane_utilisation"],
                               "lane_utilisation_note": "exec-mask utilisation (SQ_THREAD_CYCLES_VALU / 64 SQ_INSTS_VALU): the "
                                                        "box-test loop is wave-uniform, lanes that ride along count as active",
-                              "salu_per_valu": prof["salu_per_ray"] / prof["valu_per_ray"], "clock_ghz": prof["clock_ghz"]}
+                              "salu_per_valu": prof["salu_per_ray"] / prof["valu_per_ray"]}
                 # the scalar unit: one per CU, one instruction per cycle, shared by the CU's four SIMDs
                 salu_rate = prof["salu_per_ray"] * rays_per_launch / sec_per_launch / 1e9
-                rf["scalar"] = {"achieved": salu_rate, "peak": N_CU * prof["clock_ghz"], "unit": "G instr/s",
-                                "frac": salu_rate / (N_CU * prof["clock_ghz"])}
+                rf["scalar"] = {"achieved": salu_rate, "peak": N_CU * MAX_CLOCK_GHZ, "unit": "G instr/s",
+                                "frac": salu_rate / (N_CU * MAX_CLOCK_GHZ)}
                 rf["hbm"] = {"achieved": hbm_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
                              "bytes_per_ray": prof["hbm_bytes_per_ray"], "l2_hit_rate": prof["l2_hit_rate"]}
                 rf["wave_cycles_split"] = prof["wave_cycles_split"]
-                rf["source"] = ("%s (rocprofv3 --pmc, one counter set per pass, same build / scene / size / spp: per-ray "
-                                "counters x this run's rays per launch / this run's HIP-event launch time; the profiled "
-                                "launch took %.2f ms)" % (prof["file"], prof["profiled_kernel_ms"]))
+                rf["profile"] = {"file": prof["file"], "build": prof["build"], "workload": workload}
+                rf["source"] = ("%s (rocprofv3 --pmc, one counter set per pass, same build / scene / size / spp / knobs — checked by "
+                                "sha256: per-ray counters x this run's rays per launch / this run's HIP-event launch time; the "
+                                "profiled launch took %.2f ms)" % (prof["file"], prof["profiled_kernel_ms"]))
             else:
-                rf.update(bound="valu", achieved=None, peak=None, unit="G wave64-instr/s", frac=None, traffic=None,
-                          source="no committed counter profile for this pipeline")
+                rf.update(bound="valu", achieved=None, peak=N_SIMD * MAX_CLOCK_GHZ / 2.0, unit="G wave64-instr/s", frac=None, traffic=None,
+                          source="no usable counter profile: %s" % json.dumps(why), **why)
             rf["algorithmic"] = {
                 "bytes_per_ray": b_ray, "n_node": n_node, "n_prim": n_prim, "h": h,
                 "bytes_per_launch": b_ray * rays_per_launch,

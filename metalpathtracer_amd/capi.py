@@ -84,6 +84,31 @@ class Stats(C.Structure):
 _lib = None
 
 
+def knob_env():
+    """The MPT_* environment knobs that change what the device runs, i.e. part of a measured workload."""
+    return {k: v for k, v in sorted(os.environ.items())
+            if k.startswith("MPT_") and k != "MPT_LIB" and not k.startswith("MPT_BENCH_") and k != "MPT_CPU_THREADS"}
+
+
+def build_id():
+    """What ties a committed counter profile (profiles/*.json) to the build it was taken from: the sha256 of the library that
+    is loaded and the sha256 of the sources it is built from (kernels, host side, ABI header, compiler flags) — the second
+    survives a rebuild on another machine."""
+    import hashlib
+    import re
+    root = os.path.dirname(_PKG)
+    h = hashlib.sha256()
+    csrc = os.path.join(_PKG, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip")))
+    files.append(os.path.join(root, "include", "mpt.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    m = re.search(r"^HIPFLAGS\s*\?=.*$", open(os.path.join(root, "Makefile")).read(), flags=re.M)
+    h.update((m.group(0) if m else "").encode())
+    lib = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest() if os.path.exists(LIB_PATH) else None
+    return {"lib_sha256": lib, "source_sha256": h.hexdigest()}
+
+
 def load():
     """dlopen libmpt_hip.so and declare prototypes.  Raises if the library is missing."""
     global _lib

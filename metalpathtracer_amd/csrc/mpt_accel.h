@@ -50,7 +50,13 @@ struct Item {
     uint32_t key;     // caller's handle (position of the leaf in the caller's list)
 };
 
-#define MPT_ACCEL_NODE_FLOATS 28u
+// node stride in global memory: 8 float4 = 128 B, so that a node is exactly one cache line (7 float4 of data; a 112-byte
+// stride makes 7 nodes of 8 straddle two lines: twice the tag look-ups and twice the L2 -> L1 bytes per visit).  The LDS
+// image keeps the 7-float4 stride (bank spread, mpt_ordered.h ot_stage).
+#ifndef MPT_OT_NODE_STRIDE
+#define MPT_OT_NODE_STRIDE 8u
+#endif
+#define MPT_ACCEL_NODE_FLOATS (4u * MPT_OT_NODE_STRIDE)
 #define MPT_ACCEL_LEAF 0x80000000u
 #define MPT_ACCEL_EMPTY 0xFFFFFFFFu
 #define MPT_ACCEL_MAX_ALWAYS 16u
@@ -221,7 +227,7 @@ static inline Topology build_topology(const std::vector<Item>& items) {
 
 // nodes in the device format; first_of[item] = position of the item's first primitive in the device array
 static inline std::vector<float> emit(const Topology& tp, const std::vector<Item>& items, const std::vector<uint32_t>& first_of) {
-    std::vector<float> out((size_t)tp.wn.size() * MPT_ACCEL_NODE_FLOATS);
+    std::vector<float> out((size_t)tp.wn.size() * MPT_ACCEL_NODE_FLOATS, 0.0f);
     for (size_t i = 0; i < tp.wn.size(); ++i) {
         const Topology::WNode& w = tp.wn[i];
         float* o = out.data() + i * MPT_ACCEL_NODE_FLOATS;

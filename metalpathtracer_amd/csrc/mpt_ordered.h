@@ -92,7 +92,7 @@ struct OtBudgets {
 };                                        // walks it at once (as a ring-M0 step would) instead of parking them; 65 = never
 
 struct AccelDev {
-    const float4* nodes;    // 7 float4 per node, breadth-first (mpt_accel.h)
+    const float4* nodes;    // MPT_OT_NODE_STRIDE float4 per node (7 used), breadth-first (mpt_accel.h)
     const float4* refleaf;  // 2 float4 per reference leaf: (bmin, 0) (bmax, 0)
     const float4* always;   // 5 float4 per sphere of the always list: (c, leaf<<1) (r, bits(index), bits(k), mat) (0,0,0, orig id)
                             // + the box of its reference leaf (bmin, 0) (bmax, 0)
@@ -158,7 +158,7 @@ __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds,
         nd.hz = make_float4(f.x, f.y, f.z, f.w);
         nd.ref = make_uint4(__float_as_uint(g.x), __float_as_uint(g.y), __float_as_uint(g.z), __float_as_uint(g.w));
     } else {
-        const float4* q = ac.nodes + 7u * (size_t)n;
+        const float4* q = ac.nodes + MPT_OT_NODE_STRIDE * (size_t)n;
         nd.lx = q[0];
         nd.ly = q[1];
         nd.lz = q[2];
@@ -365,6 +365,24 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
         if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF) {  // a leaf: primitives [first, first + count) in index order
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
             if (COUNT && first_active_lane()) wc.outer_iters++;
+#ifdef MPT_OT_LEAF2   // two primitives per trip: both records are requested before either is tested (leaves hold <= 2
+                      // primitives with the product's builders: one memory round trip per leaf instead of two)
+            for (uint32_t k = 0; k < count; k += 2u) {
+                const bool two = k + 1u < count;
+                const Prim3 pa = load_prim(sc, lds, first + k);
+                Prim3 pb = pa;
+                if (two) pb = load_prim(sc, lds, first + k + 1u);
+                if (COUNT && first_active_lane()) wc.prim_iters++;
+                if (!(ac.n_always != 0u && prim_type(pa.p0) == 0)) {
+                    if (COUNT) wc.prim_tests++;
+                    ot_test_prim(pa, first + k, o, d, T, W, tie);
+                }
+                if (two && !(ac.n_always != 0u && prim_type(pb.p0) == 0)) {
+                    if (COUNT) wc.prim_tests++;
+                    ot_test_prim(pb, first + k + 1u, o, d, T, W, tie);
+                }
+            }
+#else
 #ifdef MPT_OT_PREFETCH   // loading primitive k + 1 while k is tested: measured slower (12 more VGPRs live: 28.7 vs 28.1 ms)
             Prim3 nxt = load_prim(sc, lds, first);
 #endif
@@ -385,6 +403,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                 if (COUNT) wc.prim_tests++;
                 ot_test_prim(pr, first + k, o, d, T, W, tie);
             }
+#endif
             cur = ot_pop_next(st, sp, ot_cull_limit(T, ac.eps_abs));
         }
         OT_WTOC(ot_leaf_cycles);
@@ -480,7 +499,10 @@ __device__ __forceinline__ void closest_hit_ordered(const AccelDev& ac, const Sc
 
 __device__ __forceinline__ void ot_stage(const SceneDev& sc, const AccelDev& ac, float4* lds) {
     const uint32_t n4 = ac.n_lds_nodes * 7u, p4 = sc.n_lds_prims * 3u;
-    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = ac.nodes[i];
+    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {  // 7 of a node's MPT_OT_NODE_STRIDE float4 (the rest is padding)
+        const uint32_t node = i / 7u;
+        lds[i] = ac.nodes[node * MPT_OT_NODE_STRIDE + (i - node * 7u)];
+    }
     for (uint32_t i = threadIdx.x; i < ac.n_always * 5u; i += blockDim.x) lds[ac.lds_always_off + i] = ac.always[i];
     for (uint32_t i = threadIdx.x; i < p4; i += blockDim.x) lds[sc.lds_prim_off + i] = sc.prims[i];
     for (uint32_t i = threadIdx.x; i < sc.n_lds_mats * 2u; i += blockDim.x) lds[sc.lds_mat_off + i] = sc.mats[i];

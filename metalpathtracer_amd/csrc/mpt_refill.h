@@ -1,0 +1,397 @@
+// mpt_refill.h — k_ordered_rf: the closest-first pipeline (mpt_ordered.h) with LANE REFILL in its tree-walk steps.  gfx950 only.
+//
+// Why: on scenes whose tree comes from L2 (bunny x20, 1 M triangles) the walk is 62 % of k_ordered's time and runs at
+// ~50 % lane utilisation: the walks of 64 rays differ in length by 10x, and a step waits for its slowest lanes (budgets
+// and parking — rings M0 / M1 of k_ordered — recover half of that, at 144 bytes of ring traffic per parked ray).  A node
+// trip costs the wave ~2,500 cycles (seven divergent 16-byte loads per lane, ~470 cycles each in the vector L1, then 130
+// vector instructions) whether 20 or 64 lanes take part.  So the lanes are kept busy instead:
+//
+//   tree-walk step (ring M, started once M holds MPT_RF_TRIGGER rays):
+//     repeat
+//       REFILL   lanes without a ray pop one from ring M (origin, direction, best t / primitive so far, walk state)
+//       WALK     ot_walk (mpt_ordered.h) until fewer than `refill_min` lanes still walk — or `park_min` once M is empty
+//       COLLECT  a lane whose walk is complete keeps (t, primitive, record position) in a one-deep HIT BUFFER in
+//                registers and is free for the next ray; a lane that finishes a second ray before the buffer is emptied waits
+//       SHADE    when `shade_min` lanes hold a buffered hit (or lanes wait): final check, one bounce of shading for all of
+//                them at once — the rest of the record is read back from ring M, where it has stayed — survivors -> ring R
+//     until M is empty and fewer than `park_min` lanes walk; those few are parked in M again with their stacks.
+//
+// Unfinished walks stay in their lanes: no budget ladder, no ring hop per pause.  Shading still runs at (nearly) full
+// width, because hits are buffered until enough of them have come together.  Every ray sees exactly the sequence of
+// tests it would see in k_ordered (its walk state is private), so images are bit-identical.
+// Ring capacity: primary and ring-R steps run only while M < trigger and add <= 64 rays each, so M <= trigger + 63; a
+// tree-walk step moves rays from M to R / E one for one: R <= 127 + M.  With trigger <= 256 all stay below MPT_WL_RING.
+#pragma once
+#include "mpt_ordered.h"
+
+struct RfKnobs {
+    uint32_t trigger;      // a tree-walk step starts when ring M holds this many rays (<= 256)
+    uint32_t refill_min;   // while M has rays: the walk pauses for a refill once fewer lanes than this still walk
+    uint32_t shade_min;    // buffered hits that start a shading phase
+    uint32_t park_min;     // M empty and fewer walking lanes than this: park them, end the step
+    uint32_t block_max;    // lanes waiting for their hit buffer that force a shading phase
+};
+
+template <bool COUNT, bool ALL_LDS>
+__global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(PassParams pp, AccelDev ac, OtRings ring, RfKnobs kn,
+                                                                             uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
+    extern __shared__ float4 lds_raw[];
+    ot_stage(pp.scene, ac, lds_raw);
+    const LdsNodes lds = (LdsNodes)lds_raw;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_paths = pp.desc->total_paths;
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const OtStack st = ot_stack(ac, lds_raw, wave_id);
+    const uint32_t wbase = wave_id * (MPT_OT_RINGS * MPT_WL_RING);
+    const uint32_t rbase = wbase + MPT_OT_RING_R * MPT_WL_RING, ebase = wbase + MPT_OT_RING_E * MPT_WL_RING,
+                   mbase = wbase + MPT_OT_RING_M * MPT_WL_RING;
+    uint32_t cnt_r = 0, cnt_e = 0, cnt_m = 0;   // wave-uniform ring fills (the rings are stacks: newest first)
+    uint32_t cur = 0, end = 0;
+    const uint32_t n_tiles = total_paths / (pp.S * 64u);
+    const uint32_t waves_per_group = (n_waves + MPT_NGROUP - 1u) / MPT_NGROUP;
+    uint32_t grp = blockIdx.x & (MPT_NGROUP - 1u);
+    uint32_t seen = 0;
+    bool exhausted = false;
+    uint32_t tile_cached = 0xFFFFFFFFu, tile_xy_cached = 0u;
+    uint32_t n_rays = 0, n_paths = 0, n_flagged = 0, n_parked = 0;
+    WorkCount wc = {};
+
+    // a full record: what a ray needs to be shaded and to go on (64 bytes)
+    auto write_record = [&](uint32_t to, const PathState& ps, const PathRngDev& g) {
+        ring.od[to] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+        ring.dt[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+        ring.tl[to] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+        ring.ia[to] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+    };
+    auto read_record = [&](uint32_t at, PathState& ps, PathRngDev& g) {
+        const float4 a = ring.od[at], b = ring.dt[at], cc = ring.tl[at];
+        const uint4 ia = ring.ia[at];
+        ps.o = f3(a.x, a.y, a.z);
+        ps.d = f3(a.w, b.x, b.y);
+        ps.thr = f3(b.z, b.w, cc.x);
+        ps.L = f3(cc.y, cc.z, cc.w);
+        ps.La = __uint_as_float(ia.y);
+        ps.path = ia.x;
+        ps.bounce = ia.w >> 27;
+        g.pixel = ia.z;
+        g.sample = ia.w & 0x07FFFFFFu;
+        g.lit_seed = 0;
+        if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+    };
+    // wave64 compaction of the lanes with `go` onto the top of a ring (ballot + mbcnt prefix); returns the lane's slot
+    auto ring_slot = [&](bool go, uint32_t base, uint32_t& cnt) -> uint32_t {
+        const unsigned long long m = __ballot(go);
+        const uint32_t to = base + cnt + wave_rank(m);
+        cnt += (uint32_t)__popcll(m);
+        return to;
+    };
+
+    for (;;) {
+        // ---- step choice ---------------------------------------------------------------------------------------------
+        uint32_t kind = MPT_OT_NONE;  // ring to pop from; NONE = primary step
+        if (cnt_e >= 64u) kind = MPT_OT_RING_E;
+        else if (cnt_m >= kn.trigger) kind = MPT_OT_RING_M;
+        else if (cnt_r >= 64u) kind = MPT_OT_RING_R;
+        if (kind == MPT_OT_NONE) {
+            if (!exhausted && cur == end) {  // guided self-scheduling of path ids, as k_wavelocal (mpt_kernels.h)
+                uint32_t k = 0, blk = 0, rend = 0;
+                bool got = false;
+                if (lane == 0) {
+                    for (uint32_t t = 0; t < MPT_NGROUP && !got; ++t) {
+                        const uint32_t re = range_paths(n_tiles, pp.S, grp);
+                        const uint32_t left = seen < re ? re - seen : 0u;
+                        blk = (left / (wl_div * waves_per_group)) & ~63u;
+                        blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
+                        if (t > 0u) blk = wl_min;
+                        k = atomicAdd(&pp.ctr[MPT_CTR_CURSOR(grp)], blk);
+                        if (k < re) {
+                            got = true;
+                            rend = re;
+                        } else {
+                            grp = (grp + 1u) & (MPT_NGROUP - 1u);
+                            seen = 0;
+                        }
+                    }
+                }
+                got = __builtin_amdgcn_readfirstlane((int)got) != 0;
+                k = __builtin_amdgcn_readfirstlane(k);
+                blk = __builtin_amdgcn_readfirstlane(blk);
+                rend = __builtin_amdgcn_readfirstlane(rend);
+                grp = __builtin_amdgcn_readfirstlane(grp);
+                seen = k;
+                if (!got) {
+                    exhausted = true;
+                } else {
+                    cur = k;
+                    end = (k + blk < rend) ? k + blk : rend;
+                }
+            }
+            if (exhausted) {  // drain: tree walks first (they feed ring R), then fresh rays, then the flagged ones
+                if (cnt_m != 0u) kind = MPT_OT_RING_M;
+                else if (cnt_r != 0u) kind = MPT_OT_RING_R;
+                else if (cnt_e != 0u) kind = MPT_OT_RING_E;
+                else break;
+            }
+        }
+
+        if (kind == MPT_OT_RING_M) {
+            // =========================================================================================================
+            // tree-walk step with lane refill
+            // =========================================================================================================
+            F3 wo = f3(1, 1, 1), wd = f3(1, 1, 1);
+            float wT = INFINITY;
+            int wW = -1;
+            uint32_t wcur = MPT_OT_DONE, wsp = 0u, wat = 0u, wstat = 0u;
+            bool wlost = false, wagain = false;
+            bool walking = false, blocked = false;
+            float hT = INFINITY;   // the hit buffer
+            int hW = -1;
+            uint32_t hat = 0u, hstat = 0u;   // 0 empty, 1 a finished walk (final check pending), 2 goes to the reference-order walk
+            const uint32_t park_min = exhausted ? 1u : kn.park_min;
+
+            // one bounce of shading for every buffered hit
+            auto shade_buffered = [&]() {
+                const bool has = hstat != 0u;
+                if (__ballot(has) == 0ull) return;
+                PathState ps;
+                PathRngDev g;
+                bool to_r = false, to_e = false;
+                if (has) {
+                    read_record(hat, ps, g);
+                    bool exact = hstat == 2u;
+                    if (!exact && hW >= 0) {
+                        const OtRay r = ot_ray(ps.o, ps.d);
+                        exact = !ot_final_check(ac, pp.scene, lds, ps.o, ps.d, r, hT, hW);
+                    }
+                    if (exact) {
+                        to_e = true;
+                    } else {
+                        n_rays++;
+                        if (shade_bounce(pp.scene, lds, pp.sp, g, ps, hT, hW)) to_r = true;
+                        else store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+                    }
+                }
+                n_flagged += to_e ? 1u : 0u;
+                const uint32_t slot_r = ring_slot(to_r, rbase, cnt_r), slot_e = ring_slot(to_e, ebase, cnt_e);
+                if (to_r || to_e) write_record(to_r ? slot_r : slot_e, ps, g);
+                hstat = 0u;
+            };
+
+            for (;;) {
+                // ---- REFILL ---------------------------------------------------------------------------------------------
+                {
+                    const bool idle = !walking && !blocked;
+                    const unsigned long long im = __ballot(idle);
+                    const uint32_t n_idle = (uint32_t)__popcll(im);
+                    const uint32_t take = n_idle < cnt_m ? n_idle : cnt_m;
+                    if (take != 0u) {
+                        const uint32_t rk = wave_rank(im);
+                        const bool get = idle && rk < take;
+                        uint32_t deepest = 0u;
+                        if (get) {
+                            wat = mbase + (cnt_m - 1u - rk);   // newest first: still in L2
+                            const float4 a = ring.od[wat], b = ring.dt[wat];
+                            const uint4 tv = ring.tv[wat];
+                            wo = f3(a.x, a.y, a.z);
+                            wd = f3(a.w, b.x, b.y);
+                            wT = __uint_as_float(tv.x);
+                            wW = (int)tv.y;
+                            wcur = tv.z;
+                            wsp = tv.w & 0xFFFFu;
+                            wlost = (tv.w & 0x40000000u) != 0u;
+                            wagain = (tv.w & 0x80000000u) != 0u;
+                            walking = true;
+                            deepest = wsp;
+                        }
+                        deepest = wave_max_u32(deepest);   // (only rays parked at the end of an earlier step bring a stack)
+#pragma unroll
+                        for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
+                            if (2u * k >= deepest) break;
+                            if (get && wsp > 2u * k) {
+                                const uint4 e = ring.sk[k][wat];
+                                st.lds[(2u * k) * 64u] = v2u{e.x, e.y};
+                                st.lds[(2u * k + 1u) * 64u] = v2u{e.z, e.w};
+                            }
+                        }
+                        cnt_m -= take;
+                    }
+                }
+                // ---- WALK -----------------------------------------------------------------------------------------------
+                bool tie = false;
+                if (__ballot(walking) != 0ull) {
+                    const uint32_t min_act = cnt_m != 0u ? kn.refill_min : park_min;
+                    const OtRay r = ot_ray(wo, wd);
+                    if (!walking) wcur = MPT_OT_DONE;
+                    ot_walk<COUNT, true, ALL_LDS>(ac, pp.scene, lds, st, wo, wd, r, wcur, wsp, wT, wW, tie, wlost, 0x7FFFFFFFu, min_act, wc);
+                }
+                // ---- COLLECT: finished walks -> hit buffer ----------------------------------------------------------------------
+                if (walking && (tie || wcur == MPT_OT_DONE)) {
+                    uint32_t status = 1u;
+                    if (tie) {
+                        status = 2u;                 // (whatever is left of the walk does not matter then)
+                    } else if (wlost) {              // the stack dropped entries: once more from the root, now with the t found
+                        if (wagain) {
+                            status = 2u;
+                        } else {
+                            wcur = 0u;
+                            wsp = 0u;
+                            wlost = false;
+                            wagain = true;
+                            status = 0u;
+                        }
+                    }
+                    if (status != 0u) {
+                        walking = false;
+                        blocked = true;
+                        wstat = status;
+                    }
+                }
+                if (blocked && hstat == 0u) {
+                    hT = wT;
+                    hW = wW;
+                    hat = wat;
+                    hstat = wstat;
+                    blocked = false;
+                }
+                // ---- SHADE ----------------------------------------------------------------------------------------------
+                const uint32_t n_hits = (uint32_t)__popcll(__ballot(hstat != 0u));
+                const uint32_t n_blocked = (uint32_t)__popcll(__ballot(blocked));
+                const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+                const bool ending = cnt_m == 0u && n_walk < park_min;
+                if (n_hits >= kn.shade_min || n_blocked >= kn.block_max || (ending && n_hits != 0u)) {
+                    shade_buffered();   // (the only call site: one copy of the shading code in this loop)
+                    if (blocked) {      // hstat is 0 everywhere now: the waiting lanes move up
+                        hT = wT;
+                        hW = wW;
+                        hat = wat;
+                        hstat = wstat;
+                        blocked = false;
+                    }
+                    continue;           // (an ending step comes back here until nothing is buffered any more)
+                }
+                if (!ending) continue;
+                // ---- end of the step: the few lanes still walking are parked in ring M again, with their stacks -----------------
+                if (n_walk != 0u) {
+                    float4 b = make_float4(0, 0, 0, 0), cc = b;
+                    uint4 ia = make_uint4(0, 0, 0, 0);
+                    if (walking) {   // (every read of the old records before any write: the new slots may be the old ones)
+                        b = ring.dt[wat];
+                        cc = ring.tl[wat];
+                        ia = ring.ia[wat];
+                    }
+                    const uint32_t to = ring_slot(walking, mbase, cnt_m);
+                    if (walking) {
+                        ring.od[to] = make_float4(wo.x, wo.y, wo.z, wd.x);
+                        ring.dt[to] = make_float4(wd.y, wd.z, b.z, b.w);
+                        ring.tl[to] = cc;
+                        ring.ia[to] = ia;
+                        ring.tv[to] = make_uint4(__float_as_uint(wT), (uint32_t)wW, wcur, wsp | (wlost ? 0x40000000u : 0u) | (wagain ? 0x80000000u : 0u));
+#pragma unroll
+                        for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
+                            if (wsp > 2u * k) {
+                                const v2u e0 = st.lds[(2u * k) * 64u], e1 = st.lds[(2u * k + 1u) * 64u];
+                                ring.sk[k][to] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+                            }
+                        }
+                    }
+                }
+                break;
+            }
+            if ((cnt_r > cnt_e ? cnt_r : cnt_e) > MPT_WL_RING || cnt_m > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen
+            continue;
+        }
+
+        // =============================================================================================================
+        // primary step / ring R step (top test) / ring E step (reference-order walk): 64 rays, shaded where they finish
+        // =============================================================================================================
+        PathState ps;
+        PathRngDev g;
+        bool valid = false;
+        float T = INFINITY;
+        int W = -1;
+        if (kind == MPT_OT_NONE) {
+            const uint32_t pchunk = range_chunk_to_path_chunk(pp, cur >> 6, grp);  // = tile * S + sample
+            cur += 64u;
+            uint32_t tl, sidx;
+            if (pp.s_shift != 0xFFu) {
+                tl = pchunk >> pp.s_shift;
+                sidx = pchunk & (pp.S - 1u);
+            } else {
+                tl = pchunk / pp.S;
+                sidx = pchunk - tl * pp.S;
+            }
+            if (tl != tile_cached) {
+                tile_cached = tl;
+                tile_xy_cached = (uint32_t)__builtin_amdgcn_readfirstlane((int)pp.tile_xy[tl]);
+            }
+            ps.path = pchunk * 64u + lane;
+            const uint32_t px = (tile_xy_cached & 0xFFFFu) * 8u + (lane & 7u), py = (tile_xy_cached >> 16) * 8u + (lane >> 3);
+            if (px < pp.width && py < pp.height) {
+                gen_primary(pp, px, py, pp.sample_begin + sidx, ps, g);
+                valid = true;
+                n_paths++;
+            }
+        } else {
+            const uint32_t c = kind == MPT_OT_RING_R ? cnt_r : cnt_e;
+            const uint32_t take = c < 64u ? c : 64u;
+            valid = lane < take;
+            const uint32_t at = (kind == MPT_OT_RING_R ? rbase : ebase) + (c - take + lane);
+            if (kind == MPT_OT_RING_R) cnt_r = c - take;
+            else cnt_e = c - take;
+            if (valid) read_record(at, ps, g);
+        }
+        bool shade = false, to_m = false, to_e = false;
+        if (kind == MPT_OT_RING_E) {
+            if (valid) {  // reference-order walk (PathTracing.h:75-204 as closest_hit_resume restates it)
+                uint32_t node = 0;
+                closest_hit_resume<COUNT, false, false>(pp.scene, lds, ps.o, ps.d, node, T, W, 0xFFFFFFFFu, wc);
+                shade = true;
+            }
+        } else if (valid) {
+            // TOP TEST: always-list spheres + the root's boxes
+            bool tie = false, need = false;
+            if (ot_degenerate(ps.o, ps.d, ac.o_limit)) {
+                to_e = true;
+            } else {
+                const OtRay r = ot_ray(ps.o, ps.d);
+                ot_top_test<COUNT>(ac, lds, ps.o, ps.d, r, T, W, tie, need, wc);
+                if (tie) to_e = true;
+                else if (need) to_m = true;
+                else if (W >= 0 && !ot_final_check(ac, pp.scene, lds, ps.o, ps.d, r, T, W)) to_e = true;
+                else shade = true;
+            }
+        }
+        bool to_r = false;
+        if (shade) {
+            n_rays++;
+            if (shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W)) to_r = true;
+            else store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+        }
+        n_flagged += to_e ? 1u : 0u;
+        n_parked += to_m ? 1u : 0u;
+        if (__ballot(to_r || to_e || to_m) != 0ull) {
+            const uint32_t slot_r = ring_slot(to_r, rbase, cnt_r), slot_e = ring_slot(to_e, ebase, cnt_e),
+                           slot_m = ring_slot(to_m, mbase, cnt_m);
+            if (to_r || to_e || to_m) {
+                const uint32_t to = to_r ? slot_r : to_e ? slot_e : slot_m;
+                write_record(to, ps, g);
+                if (to_m) ring.tv[to] = make_uint4(__float_as_uint(T), (uint32_t)W, 0u, 0u);   // the walk starts at the root
+            }
+        }
+        const uint32_t worst = cnt_r > cnt_e ? (cnt_r > cnt_m ? cnt_r : cnt_m) : (cnt_e > cnt_m ? cnt_e : cnt_m);
+        if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (capacity note at the top)
+    }
+    flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
+    {
+        unsigned long long a = n_flagged, b = n_parked;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+        }
+        if (lane == 0) {
+            if (a) atomicAdd(&pp.desc->flagged, a);
+            if (b) atomicAdd(&pp.desc->parked, b);
+        }
+    }
+}

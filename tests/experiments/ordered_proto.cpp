@@ -94,7 +94,7 @@ static void collect_leaves() {
     }
 }
 
-static std::vector<float> g_acc;         // emitted device nodes (mpt_accel::emit): 28 floats each
+static std::vector<float> g_acc;         // emitted device nodes (mpt_accel::emit): MPT_ACCEL_NODE_FLOATS each
 static std::vector<uint32_t> g_first_leaf;  // "first" of a leaf ref -> leaf index (the prototype keeps primitives where they are)
 
 struct Stats {
@@ -202,7 +202,7 @@ static void ordered_hit(const float o[3], const float d[3], float& t_out, int& p
         int sp = 0;
         uint32_t cur = 0;
         auto lim_of = [&](float T) { return T + (T * EPS_REL + EPS_ABS); };
-        auto child_ref = [&](uint32_t n, uint32_t slot) { uint32_t r; memcpy(&r, &g_acc[28 * (size_t)n + 24 + slot], 4); return r; };
+        auto child_ref = [&](uint32_t n, uint32_t slot) { uint32_t r; memcpy(&r, &g_acc[MPT_ACCEL_NODE_FLOATS * (size_t)n + 24 + slot], 4); return r; };
         auto pop = [&](float lim) -> uint32_t {
             while (sp > 0) {
                 --sp;
@@ -215,7 +215,7 @@ static void ordered_hit(const float o[3], const float d[3], float& t_out, int& p
         };
         for (;;) {
             while (cur < 0x80000000u) {
-                const float* n = &g_acc[28 * (size_t)cur];
+                const float* n = &g_acc[MPT_ACCEL_NODE_FLOATS * (size_t)cur];
                 nv++;
                 const float lim = lim_of(tv.T);
                 uint32_t k[4];
@@ -383,7 +383,7 @@ int main(int argc, char** argv) {
         if (refs != acc_items.size() || topo.item_order.size() != acc_items.size()) return fprintf(stderr, "builder: item count\n"), 1;
     }
     printf("%s: %zu prims, %zu ref nodes, %zu ref leaves (%zu with spheres), own tree: %zu nodes of width %d\n", xml, P, N,
-           g_leaves.size(), g_always.size(), g_acc.size() / 28, K);
+           g_leaves.size(), g_always.size(), g_acc.size() / MPT_ACCEL_NODE_FLOATS, K);
     Uniforms u;
     memset(&u, 0, sizeof u);
     const float pos[3] = {0, 20, 50}, fwd[3] = {0, 0, -1}, up[3] = {0, 1, 0};

@@ -31,18 +31,29 @@ def test_bench_line_single_gpu():
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Mrays/s" and d["value"] > 0
     rf = d["roofline"]
-    # a bound that binds: vector-ALU issue or measured HBM traffic, whichever is larger — never above 1
+    # a bound that binds: vector-ALU issue at the chip's 2.4 GHz or measured HBM traffic, whichever is larger — never above 1
     assert rf["bound"] in ("valu", "hbm") and rf["launches"] == 2 and rf["kernel"] == "k_wavelocal"   # AUTO: < 8192 primitives
-    if rf["frac"] is not None:      # a counter profile of this pipeline is committed under profiles/
+    if rf["frac"] is not None:      # a counter profile of THIS workload and THIS build is committed under profiles/
         assert 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
         assert rf["frac"] == max(rf["valu"]["frac"], rf["hbm"]["frac"])
+        assert rf["valu"]["peak"] == 1024 * 2.4 / 2 and rf["valu"]["frac_at_measured_clock"] >= rf["valu"]["frac"]
         assert rf["hbm"]["peak"] == 8000.0 and 0.0 < rf["valu"]["lane_utilisation"] <= 1.0
         assert rf["traffic"] > 0 and "profiles/" in rf["source"]
+        from metalpathtracer_amd import capi
+        bid, pb = capi.build_id(), rf["profile"]["build"]
+        assert pb["source_sha256"] == bid["source_sha256"] or pb["lib_sha256"] == bid["lib_sha256"]
+    else:                           # ... otherwise the line says why, and prints no fraction it cannot stand behind
+        assert rf.get("profile_stale") is True or "profile_missing" in rf
+        assert rf["achieved"] is None and rf["traffic"] is None
     assert rf["algorithmic"]["bytes_per_ray"] > 168.0
     assert d["serial_ms_per_render"] > 0 and d["config"]["serial_mrays_per_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
     assert d["config"]["paths"] == 640 * 360 * 8 * 2
+    ex = d["extra_workloads"]       # untimed extras: the Cornell-style scene and bunny x20 at 1920x1080 x 256 spp, one serial render each
+    assert [e["workload"].split()[0] for e in ex] == ["cornell.xml", "bunny20.xml"]
+    assert all(e["ms_per_render"] > 0 and e["mrays_per_s"] > 0 and e["paths"] == 1920 * 1080 * 256 for e in ex)
+    assert "closest-first" in ex[1]["pipeline"] and "reference-order" in ex[0]["pipeline"]
 
 
 def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():

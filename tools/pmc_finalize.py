@@ -8,6 +8,8 @@ note = sys.argv[3] if len(sys.argv) > 3 else ""
 pmc = json.load(open(os.path.join(ROOT, "gpurun_out", tag + "_pmc.json")))
 log = open(os.path.join(ROOT, "gpurun_out", "pmc_%s_1.log" % tag)).read()
 m = re.findall(r"pipe (\d+) spp (\d+) depth (\d+): total_ms ([\d.]+) trace_ms ([\d.]+) launches (\d+) rays (\d+)", log)[-1]
+wl = re.findall(r"^WORKLOAD (\{.*\})$", log, flags=re.M)
+workload = json.loads(wl[-1]) if wl else None
 c = pmc["counters"]
 rays, ms = int(m[6]) / int(m[5]), float(m[4]) / int(m[5])
 clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e-3) / 1e9
@@ -15,6 +17,8 @@ d = {
     "note": ("rocprofv3 --pmc, one counter set per pass, no tracing (tools/pmc_round.sh on tools/prof_run.py); counters are of ONE launch of "
              "%s (the last of the pass); kernel_ms = HIP-event time of that launch in the pass that collected GRBM_GUI_ACTIVE. %s" % (pmc["kernel"], note)).strip(),
     "kernel": pmc["kernel"], "pipeline": int(m[0]), "spp": int(m[1]), "depth": int(m[2]),
+    "workload": workload,   # scene / size / spp / depth / pipeline / tree builder and the build (library + source sha256): bench.py
+                            # uses a profile only for a run of the same workload with the same build
     "rays_per_launch": rays, "kernel_ms": ms, "counters": c,
     "derived": {
         "clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel time": clock,

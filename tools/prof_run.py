@@ -10,6 +10,10 @@ ctx = capi.Context(0); ctx.upload_scene(*sc.buffers())
 W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
 ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
 spp = int(os.environ.get("SPP", "16")); pipe = int(os.environ.get("PIPE", "1")); depth = int(os.environ.get("DEPTH", "8"))
+import json
+print("WORKLOAD " + json.dumps(dict(scene=scene, width=W, height=H, spp=spp, depth=depth, pipeline=pipe, bvh=int(os.environ.get("BVH", "0")),
+                                    prims=sc.getPrimitiveCount(), env=capi.knob_env(),
+                                    **capi.build_id())), flush=True)
 for rep in range(int(os.environ.get("REPS", "2"))):
     ctx.clear_sum(); ctx.reset_stats()
     ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=depth, sample_count=spp, pipeline=pipe, slots_per_iter=int(os.environ.get("SLOTS", "0")))
