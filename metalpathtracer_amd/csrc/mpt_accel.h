@@ -50,11 +50,11 @@ struct Item {
     uint32_t key;     // caller's handle (position of the leaf in the caller's list)
 };
 
-// node stride in global memory: 8 float4 = 128 B, so that a node is exactly one cache line (7 float4 of data; a 112-byte
-// stride makes 7 nodes of 8 straddle two lines: twice the tag look-ups and twice the L2 -> L1 bytes per visit).  The LDS
-// image keeps the 7-float4 stride (bank spread, mpt_ordered.h ot_stage).
+// node stride in global memory, in float4: 7 = packed (112 B).  8 (one node = one 128-byte cache line; the LDS image keeps
+// the 7-float4 stride either way) was measured on bunny x20: 66.3 ms against 65.1 — the lines it saves are already L1 /
+// L2 hits (4.4 L2 requests per ray), the 14 % larger tree costs more.
 #ifndef MPT_OT_NODE_STRIDE
-#define MPT_OT_NODE_STRIDE 8u
+#define MPT_OT_NODE_STRIDE 7u
 #endif
 #define MPT_ACCEL_NODE_FLOATS (4u * MPT_OT_NODE_STRIDE)
 #define MPT_ACCEL_LEAF 0x80000000u

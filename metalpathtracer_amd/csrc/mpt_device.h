@@ -159,6 +159,7 @@ struct WorkCount {
 #endif
 #ifdef MPT_OT_TIMES
     unsigned long long ot_node_cycles, ot_leaf_cycles, ot_node_trips, ot_leaf_trips, ot_rounds;  // closest-first walk, per wave
+    unsigned long long ot_node_lanes, ot_leaf_lanes;  // ... lanes that took part in those trips (per lane)
 #endif
 };
 #ifdef MPT_DEBUG_WAVE_TIMES

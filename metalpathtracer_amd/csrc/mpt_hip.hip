@@ -27,7 +27,6 @@
 #include "mpt_kernels.h"
 #include "mpt_lbvh.h"
 #include "mpt_ordered.h"
-#include "mpt_refill.h"
 
 // =====================================================================================================
 // host side of the C ABI
@@ -108,9 +107,7 @@ struct mpt_ctx {
     uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, ot_lds_nodes = 0, ot_lds_prims = 0;
     uint32_t ot_stack_depth = 8;     // LDS stack entries per lane (MPT_OT_STACK); deeper entries spill to global memory
     OtBudgets ot_budgets = default_ot_budgets();
-    bool ot_refill = true;           // tree-walk steps with lane refill (k_ordered_rf, mpt_refill.h); MPT_OT_REFILL=0: k_ordered
-    RfKnobs rf = {256u, 44u, 40u, 16u, 8u};   // MPT_RF_KNOBS="trigger,refill_min,shade_min,park_min,block_max"
-    float tri_extent = 0.0f, acc_eps_abs = 0.0f;
+    float tri_extent = 0.0f, acc_eps_abs = 0.0f, acc_cull_rel = 9.765625e-4f;
     bool acc_ok = false;             // the closest-first pipeline may be used for this scene
     std::string acc_why;
     // uniforms / size
@@ -161,11 +158,6 @@ static const void* mega_kernel(bool count, bool all_lds) {
 static const void* ordered_kernel(bool count, bool all_lds) {
     if (count) return all_lds ? (const void*)k_ordered<true, true> : (const void*)k_ordered<true, false>;
     return all_lds ? (const void*)k_ordered<false, true> : (const void*)k_ordered<false, false>;
-}
-
-static const void* ordered_rf_kernel(bool count, bool all_lds) {
-    if (count) return all_lds ? (const void*)k_ordered_rf<true, true> : (const void*)k_ordered_rf<true, false>;
-    return all_lds ? (const void*)k_ordered_rf<false, true> : (const void*)k_ordered_rf<false, false>;
 }
 
 static const void* wavelocal_kernel(bool count, bool all_lds) {
@@ -293,16 +285,7 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
             }
         }
     if ((e = getenv("MPT_OT_INPLACE")) && atoi(e) >= 1) ctx->ot_budgets.inplace_min = (uint32_t)atoi(e);
-    if ((e = getenv("MPT_OT_REFILL"))) ctx->ot_refill = atoi(e) != 0;
-    if ((e = getenv("MPT_RF_KNOBS"))) {
-        unsigned v[5] = {ctx->rf.trigger, ctx->rf.refill_min, ctx->rf.shade_min, ctx->rf.park_min, ctx->rf.block_max};
-        sscanf(e, "%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4]);
-        ctx->rf.trigger = std::min(std::max(v[0], 64u), 256u);   // ring capacity: mpt_refill.h
-        ctx->rf.refill_min = std::min(std::max(v[1], 1u), 64u);
-        ctx->rf.shade_min = std::min(std::max(v[2], 1u), 64u);
-        ctx->rf.park_min = std::min(std::max(v[3], 1u), 64u);
-        ctx->rf.block_max = std::min(std::max(v[4], 1u), 64u);
-    }
+    if ((e = getenv("MPT_OT_CULL_REL")) && atof(e) > 0.0) ctx->acc_cull_rel = (float)atof(e);
     if (ctx->wg_size < 64 || ctx->wg_size > 1024 || (ctx->wg_size & 63)) ctx->wg_size = 0;
     if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
     // allow the full 160 KiB of dynamic LDS
@@ -313,10 +296,7 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
             hipFuncSetAttribute(wavelocal_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
     for (int c = 0; c < 2; ++c)
-        for (int a = 0; a < 2; ++a) {
-            hipFuncSetAttribute(ordered_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(ordered_rf_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        for (int a = 0; a < 2; ++a) hipFuncSetAttribute(ordered_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_trace_rays_ordered, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
@@ -888,6 +868,7 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     a.lds_stack_off = image4 * 16u;
     a.stack_depth = stack_depth;
     a.eps_abs = ctx->acc_eps_abs;
+    a.cull_rel = ctx->acc_cull_rel;
     a.o_limit = ctx->tri_extent > 0.0f ? 64.0f * ctx->tri_extent : INFINITY;  // no triangles: no tree, nothing to bound
     return (size_t)a.lds_stack_off + (size_t)threads * stack_depth * 8u;
 }
@@ -1074,7 +1055,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     const bool all_lds = ctx->n_lds_nodes == ctx->n_nodes;
     const void* kfun = pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
                        : pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
-                       : pipeline == MPT_PIPE_ORDERED  ? (ctx->ot_refill ? ordered_rf_kernel : ordered_kernel)(count_flag(p), ctx->ot_lds_nodes == ctx->n_acc_nodes)
+                       : pipeline == MPT_PIPE_ORDERED  ? ordered_kernel(count_flag(p), ctx->ot_lds_nodes == ctx->n_acc_nodes)
                                                         : step_kernel(count_flag(p), all_lds);
     // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel, mpt_ordered.h: 1024)
     const int wg_max = pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : 1024;
@@ -1139,8 +1120,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
                     for (auto& p : r.sk) HIPCHK(hipMalloc(&p, n * 16));
                     L.ot_ring_waves = waves;
                 }
-                void* args[] = {(void*)&pp, (void*)&accel, (void*)&L.ot_ring, ctx->ot_refill ? (void*)&ctx->rf : (void*)&ctx->ot_budgets,
-                                (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
+                void* args[] = {(void*)&pp, (void*)&accel, (void*)&L.ot_ring, (void*)&ctx->ot_budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
                 HIPCHK(hipLaunchKernel(kfun, dim3(grid), dim3(wg), args, lds, st));
             } else {
                 void* args[] = {(void*)&pp, (void*)&L.ring, (void*)&ctx->budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
@@ -1812,7 +1792,7 @@ extern "C" int mpt_comm_destroy(mpt_comm* c) {
 }
 
 #ifdef MPT_OT_TIMES
-extern "C" int mpt_debug_ot_times(unsigned long long* out32, int reset) {
+extern "C" int mpt_debug_ot_times(unsigned long long* out32, int reset) {   // [0,24) g_ot_times, [24,32) g_ot_walk
     hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_ot_times), 24 * 8);
     if (e == hipSuccess) e = hipMemcpyFromSymbol(out32 + 24, HIP_SYMBOL(g_ot_walk), 8 * 8);
     if (e == hipSuccess && reset) {

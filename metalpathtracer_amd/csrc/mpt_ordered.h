@@ -63,7 +63,7 @@
 // lane counts per step kind (tools/gpu_ot_times.py).  Not compiled into the product library.
 #ifdef MPT_OT_TIMES
 #define OT_NREG 8   // select, fetch, top test, walk, final check, exact walk, shade, push
-__device__ unsigned long long g_ot_walk[8];     // closest-first walk: node-loop cycles, leaf-loop cycles, node trips, leaf trips, rounds
+__device__ unsigned long long g_ot_walk[8];     // closest-first walk: node-loop cycles, leaf-loop cycles, node trips, leaf trips, rounds, node lane-trips, leaf lane-trips
 __device__ unsigned long long g_ot_times[OT_NREG + 16];   // + steps[RINGS + 1] at 8, lanes[RINGS + 1] at 16
 #define OT_TIC() unsigned long long ot_t_ = __builtin_amdgcn_s_memtime()
 #define OT_TOC(r)                                                   \
@@ -72,6 +72,14 @@ __device__ unsigned long long g_ot_times[OT_NREG + 16];   // + steps[RINGS + 1] 
         ot_acc[r] += now_ - ot_t_;                                  \
         ot_t_ = now_;                                               \
     } while (0)
+__device__ __forceinline__ void ot_flush_walk_times(const WorkCount& wc, uint32_t lane) {
+    unsigned long long v[7] = {wc.ot_node_cycles, wc.ot_leaf_cycles, wc.ot_node_trips, wc.ot_leaf_trips, wc.ot_rounds, wc.ot_node_lanes, wc.ot_leaf_lanes};
+    for (int k = 0; k < 7; ++k) {
+        if (k < 2 || k == 4) v[k] = __shfl(v[k], 0);   // cycles / rounds are per wave: lane 0's copy
+        else for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+        if (lane == 0) atomicAdd(&g_ot_walk[k], v[k]);
+    }
+}
 #else
 #define OT_TIC() do { } while (0)
 #define OT_TOC(r) do { } while (0)
@@ -100,7 +108,7 @@ struct AccelDev {
     uint32_t lds_always_off;  // float4 index of the always list in LDS
     uint32_t lds_stack_off;   // byte offset of the stacks in LDS
     uint32_t stack_depth;     // LDS stack entries per lane
-    float eps_abs;            // sub-trees are culled beyond best t * (1 + 2^-10) + eps_abs
+    float eps_abs, cull_rel;  // sub-trees are culled beyond best t * (1 + cull_rel) + eps_abs (cull_rel = 2^-10 unless MPT_OT_CULL_REL says otherwise)
     float o_limit;            // ray origins farther out than this (64 x the triangle extent) exceed what the box padding covers
 };
 
@@ -195,7 +203,7 @@ __device__ __forceinline__ void ot_sort2(uint32_t& a, uint32_t& b) {
     a = lo;
     b = hi;
 }
-__device__ __forceinline__ float ot_cull_limit(float T, float eps_abs) { return T + (T * 9.765625e-4f + eps_abs); }
+__device__ __forceinline__ float ot_cull_limit(float T, const AccelDev& ac) { return T + (T * ac.cull_rel + ac.eps_abs); }
 
 // One primitive against the ray — the reference's tests, PathTracing.h:120-176, bit for bit (as leaf_test in
 // mpt_device.h), plus the tie flag.  `index` = position in the device primitive array.
@@ -266,7 +274,7 @@ __device__ __forceinline__ void ot_top_test(const AccelDev& ac, LdsNodes lds, F3
         ot_test_prim(pr, __float_as_uint(b.y), o, d, T, W, tie);
     }
     const OtNode nd = ot_load_node<true>(ac, lds, 0u);   // the root is always staged
-    const float lim = ot_cull_limit(T, ac.eps_abs);
+    const float lim = ot_cull_limit(T, ac);
     const uint32_t k0 = ot_box_key(r, nd.lx.x, nd.ly.x, nd.lz.x, nd.hx.x, nd.hy.x, nd.hz.x, nd.ref.x, lim, 0u);
     const uint32_t k1 = ot_box_key(r, nd.lx.y, nd.ly.y, nd.lz.y, nd.hx.y, nd.hy.y, nd.hz.y, nd.ref.y, lim, 1u);
     const uint32_t k2 = ot_box_key(r, nd.lx.z, nd.ly.z, nd.lz.z, nd.hx.z, nd.hy.z, nd.hz.z, nd.ref.z, lim, 2u);
@@ -334,7 +342,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             // (taking ONE source per trip for the whole wave — LDS only when every searching lane is at a staged node —
             // instead of a per-lane choice was measured on bunny x20: no difference, 20.7 ms either way)
             const OtNode nd = ot_load_node<ALL_LDS>(ac, lds, cur);
-            const float lim = ot_cull_limit(T, ac.eps_abs);
+            const float lim = ot_cull_limit(T, ac);
             uint32_t k0 = ot_box_key(r, nd.lx.x, nd.ly.x, nd.lz.x, nd.hx.x, nd.hy.x, nd.hz.x, nd.ref.x, lim, 0u);
             uint32_t k1 = ot_box_key(r, nd.lx.y, nd.ly.y, nd.lz.y, nd.hx.y, nd.hy.y, nd.hz.y, nd.ref.y, lim, 1u);
             uint32_t k2 = ot_box_key(r, nd.lx.z, nd.ly.z, nd.lz.z, nd.hx.z, nd.hy.z, nd.hz.z, nd.ref.z, lim, 2u);
@@ -347,6 +355,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             if (BUDGETED) trips++;
 #ifdef MPT_OT_TIMES
             if (first_active_lane()) wc.ot_node_trips++;
+            wc.ot_node_lanes++;
 #endif
             ot_sort2(k0, k1);
             ot_sort2(k2, k3);
@@ -365,24 +374,6 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
         if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF) {  // a leaf: primitives [first, first + count) in index order
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
             if (COUNT && first_active_lane()) wc.outer_iters++;
-#ifdef MPT_OT_LEAF2   // two primitives per trip: both records are requested before either is tested (leaves hold <= 2
-                      // primitives with the product's builders: one memory round trip per leaf instead of two)
-            for (uint32_t k = 0; k < count; k += 2u) {
-                const bool two = k + 1u < count;
-                const Prim3 pa = load_prim(sc, lds, first + k);
-                Prim3 pb = pa;
-                if (two) pb = load_prim(sc, lds, first + k + 1u);
-                if (COUNT && first_active_lane()) wc.prim_iters++;
-                if (!(ac.n_always != 0u && prim_type(pa.p0) == 0)) {
-                    if (COUNT) wc.prim_tests++;
-                    ot_test_prim(pa, first + k, o, d, T, W, tie);
-                }
-                if (two && !(ac.n_always != 0u && prim_type(pb.p0) == 0)) {
-                    if (COUNT) wc.prim_tests++;
-                    ot_test_prim(pb, first + k + 1u, o, d, T, W, tie);
-                }
-            }
-#else
 #ifdef MPT_OT_PREFETCH   // loading primitive k + 1 while k is tested: measured slower (12 more VGPRs live: 28.7 vs 28.1 ms)
             Prim3 nxt = load_prim(sc, lds, first);
 #endif
@@ -398,13 +389,13 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                 }
 #ifdef MPT_OT_TIMES
                 if (first_active_lane()) wc.ot_leaf_trips++;
+                wc.ot_leaf_lanes++;
 #endif
                 if (ac.n_always != 0u && prim_type(pr.p0) == 0) continue;  // spheres are on the always list
                 if (COUNT) wc.prim_tests++;
                 ot_test_prim(pr, first + k, o, d, T, W, tie);
             }
-#endif
-            cur = ot_pop_next(st, sp, ot_cull_limit(T, ac.eps_abs));
+            cur = ot_pop_next(st, sp, ot_cull_limit(T, ac));
         }
         OT_WTOC(ot_leaf_cycles);
         const unsigned long long going = __ballot(cur != MPT_OT_DONE && (!BUDGETED || trips < budget));
@@ -826,14 +817,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         OT_TOC(7);
     }
 #ifdef MPT_OT_TIMES
-    {
-        unsigned long long v[5] = {wc.ot_node_cycles, wc.ot_leaf_cycles, wc.ot_node_trips, wc.ot_leaf_trips, wc.ot_rounds};
-        for (int k = 0; k < 5; ++k) {
-            if (k < 2 || k == 4) v[k] = __shfl(v[k], 0);   // cycles / rounds are per wave: lane 0's copy
-            else for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
-            if (lane == 0) atomicAdd(&g_ot_walk[k], v[k]);
-        }
-    }
+    ot_flush_walk_times(wc, lane);
     if (lane == 0) {
         for (int k = 0; k < OT_NREG; ++k) atomicAdd(&g_ot_times[k], ot_acc[k]);
         for (int k = 0; k <= (int)MPT_OT_RINGS; ++k) {

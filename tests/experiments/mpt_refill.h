@@ -1,3 +1,18 @@
+// EXPERIMENT RECORD (round 3) — not part of the product, not compiled by the Makefile.
+//
+// Two restructurings of the closest-first walk that were built, verified bit-identical on the GPU (tests/test_gpu_ordered.py)
+// and then REJECTED on measurement (bunny x20, binned tree, 1920x1080 x 256 spp; k_ordered as shipped: 65.1 ms):
+//   * k_ordered_rf — tree-walk steps with lane refill and a one-deep hit buffer (below): 85.3 ms (knob sweep 84.4-101).
+//     The walkers' occupancy is fine (a walk call runs with 44-64 lanes), but refilled rays are out of phase with the lanes
+//     they join: 50.8 % of the lanes take part in a node trip against 62.8 % in k_ordered, whose M1 steps run rays sorted by
+//     the walk they have behind them — 23 % more node trips, plus 60-76 B of scratch for the extra per-lane state.
+//   * ot_walk_u — unified trips (a node OR one primitive per trip, one record buffer, at the end of this file): 78.8 ms
+//     in k_ordered, 91.3 ms with refill.  Every trip then pays the issue time of both code paths; the round trip it saves
+//     per phase is not what bounds the loop.
+// Also measured there: 128-byte node stride 66.3 ms (mpt_accel.h), two primitives per leaf trip 65.95 ms against 66.3.
+// To rebuild: copy this file next to mpt_ordered.h, include it from mpt_hip.hip and select the kernel at launch
+// (git history of round 3 has the wiring: ordered_rf_kernel / RfKnobs / MPT_OT_REFILL).
+//
 // mpt_refill.h — k_ordered_rf: the closest-first pipeline (mpt_ordered.h) with LANE REFILL in its tree-walk steps.  gfx950 only.
 //
 // Why: on scenes whose tree comes from L2 (bunny x20, 1 M triangles) the walk is 62 % of k_ordered's time and runs at
@@ -56,6 +71,9 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
     uint32_t tile_cached = 0xFFFFFFFFu, tile_xy_cached = 0u;
     uint32_t n_rays = 0, n_paths = 0, n_flagged = 0, n_parked = 0;
     WorkCount wc = {};
+#ifdef MPT_OT_TIMES
+    unsigned long long ot_acc[OT_NREG] = {}, rf_n[8] = {};   // regions: select, refill / fetch, top test, walk, collect, exact walk, shade, push / park
+#endif
 
     // a full record: what a ray needs to be shaded and to go on (64 bytes)
     auto write_record = [&](uint32_t to, const PathState& ps, const PathRngDev& g) {
@@ -88,6 +106,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
     };
 
     for (;;) {
+        OT_TIC();
         // ---- step choice ---------------------------------------------------------------------------------------------
         uint32_t kind = MPT_OT_NONE;  // ring to pop from; NONE = primary step
         if (cnt_e >= 64u) kind = MPT_OT_RING_E;
@@ -135,7 +154,11 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
             }
         }
 
+        OT_TOC(0);
         if (kind == MPT_OT_RING_M) {
+#ifdef MPT_OT_TIMES
+            rf_n[0]++;
+#endif
             // =========================================================================================================
             // tree-walk step with lane refill
             // =========================================================================================================
@@ -215,16 +238,25 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
                             }
                         }
                         cnt_m -= take;
+#ifdef MPT_OT_TIMES
+                        rf_n[2]++;
+                        rf_n[3] += take;
+#endif
                     }
                 }
+                OT_TOC(1);
                 // ---- WALK -----------------------------------------------------------------------------------------------
                 bool tie = false;
                 if (__ballot(walking) != 0ull) {
                     const uint32_t min_act = cnt_m != 0u ? kn.refill_min : park_min;
                     const OtRay r = ot_ray(wo, wd);
                     if (!walking) wcur = MPT_OT_DONE;
-                    ot_walk<COUNT, true, ALL_LDS>(ac, pp.scene, lds, st, wo, wd, r, wcur, wsp, wT, wW, tie, wlost, 0x7FFFFFFFu, min_act, wc);
+                    ot_walk_u<COUNT, true, ALL_LDS>(ac, pp.scene, lds, st, wo, wd, r, wcur, wsp, wT, wW, tie, wlost, 0x7FFFFFFFu, min_act, wc);
+#ifdef MPT_OT_TIMES
+                    rf_n[1]++;
+#endif
                 }
+                OT_TOC(3);
                 // ---- COLLECT: finished walks -> hit buffer ----------------------------------------------------------------------
                 if (walking && (tie || wcur == MPT_OT_DONE)) {
                     uint32_t status = 1u;
@@ -259,7 +291,12 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
                 const uint32_t n_blocked = (uint32_t)__popcll(__ballot(blocked));
                 const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
                 const bool ending = cnt_m == 0u && n_walk < park_min;
+                OT_TOC(4);
                 if (n_hits >= kn.shade_min || n_blocked >= kn.block_max || (ending && n_hits != 0u)) {
+#ifdef MPT_OT_TIMES
+                    rf_n[4]++;
+                    rf_n[5] += n_hits;
+#endif
                     shade_buffered();   // (the only call site: one copy of the shading code in this loop)
                     if (blocked) {      // hstat is 0 everywhere now: the waiting lanes move up
                         hT = wT;
@@ -268,10 +305,14 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
                         hstat = wstat;
                         blocked = false;
                     }
+                    OT_TOC(6);
                     continue;           // (an ending step comes back here until nothing is buffered any more)
                 }
                 if (!ending) continue;
                 // ---- end of the step: the few lanes still walking are parked in ring M again, with their stacks -----------------
+#ifdef MPT_OT_TIMES
+                rf_n[6] += n_walk;
+#endif
                 if (n_walk != 0u) {
                     float4 b = make_float4(0, 0, 0, 0), cc = b;
                     uint4 ia = make_uint4(0, 0, 0, 0);
@@ -296,6 +337,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
                         }
                     }
                 }
+                OT_TOC(7);
                 break;
             }
             if ((cnt_r > cnt_e ? cnt_r : cnt_e) > MPT_WL_RING || cnt_m > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen
@@ -341,6 +383,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
             else cnt_e = c - take;
             if (valid) read_record(at, ps, g);
         }
+        OT_TOC(1);
         bool shade = false, to_m = false, to_e = false;
         if (kind == MPT_OT_RING_E) {
             if (valid) {  // reference-order walk (PathTracing.h:75-204 as closest_hit_resume restates it)
@@ -348,6 +391,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
                 closest_hit_resume<COUNT, false, false>(pp.scene, lds, ps.o, ps.d, node, T, W, 0xFFFFFFFFu, wc);
                 shade = true;
             }
+            OT_TOC(5);
         } else if (valid) {
             // TOP TEST: always-list spheres + the root's boxes
             bool tie = false, need = false;
@@ -362,12 +406,14 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
                 else shade = true;
             }
         }
+        OT_TOC(2);
         bool to_r = false;
         if (shade) {
             n_rays++;
             if (shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W)) to_r = true;
             else store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
         }
+        OT_TOC(6);
         n_flagged += to_e ? 1u : 0u;
         n_parked += to_m ? 1u : 0u;
         if (__ballot(to_r || to_e || to_m) != 0ull) {
@@ -381,7 +427,15 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
         }
         const uint32_t worst = cnt_r > cnt_e ? (cnt_r > cnt_m ? cnt_r : cnt_m) : (cnt_e > cnt_m ? cnt_e : cnt_m);
         if (worst > MPT_WL_RING) pp.desc->overflow = 1u;  // cannot happen (capacity note at the top)
+        OT_TOC(7);
     }
+#ifdef MPT_OT_TIMES
+    ot_flush_walk_times(wc, lane);
+    if (lane == 0) {
+        for (int k = 0; k < OT_NREG; ++k) atomicAdd(&g_ot_times[k], ot_acc[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_rf[k], rf_n[k]);
+    }
+#endif
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
     {
         unsigned long long a = n_flagged, b = n_parked;
@@ -395,3 +449,125 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered_rf(Pas
         }
     }
 }
+
+// ---- ot_walk_u (was in mpt_ordered.h, in front of ot_final_check; referenced above) -----------------------------------
+#if 0
+// The same walk with UNIFIED trips (-DMPT_OT_UNIFIED): every trip a lane takes ONE unit of work — a node (four box tests) or
+// one primitive of the leaf it holds — so lanes in different phases advance side by side, and the wave pays one memory
+// round trip per trip instead of one per phase.  (The while-while form above keeps box tests and primitive tests in
+// loops of their own: on bunny x20 62 % of the lanes take part in a node trip and 35 % in a leaf trip, each trip a round
+// trip to L1 / L2 of ~2,500 cycles.)  One record buffer serves both kinds: the 7 float4 of a node or the 3 of a
+// primitive, so the loads of a trip are the same seven instructions whatever the lanes hold.  A ray sees the same
+// sequence of tests as in ot_walk; `budget` counts trips of this loop.
+template <bool COUNT, bool BUDGETED, bool ALL_LDS>
+__device__ __forceinline__ bool ot_walk_u(const AccelDev& ac, const SceneDev& sc, LdsNodes lds, const OtStack& st, F3 o, F3 d,
+                                          const OtRay& r, uint32_t& cur, uint32_t& sp, float& T, int& W, bool& tie,
+                                          bool& overflow, uint32_t budget, uint32_t min_active, WorkCount& wc) {
+    uint32_t trips = 0;   // wave-uniform
+    for (;;) {
+        const bool is_node = cur < MPT_OT_LEAF, is_leaf = !is_node && cur != MPT_OT_DONE;
+        const unsigned long long act = __ballot(is_node || is_leaf);
+        if (act == 0ull) break;
+        if (BUDGETED && (trips >= budget || (uint32_t)__popcll(act) < min_active)) break;
+        if (BUDGETED) trips++;
+        const uint32_t first = cur & 0x07FFFFFFu;
+        float4 b0, b1, b2, b3 = make_float4(0, 0, 0, 0), b4 = b3, b5 = b3, b6 = b3;
+        b0 = b1 = b2 = b3;
+        if (is_node || is_leaf) {
+            const bool in_lds = is_node ? (ALL_LDS || cur < ac.n_lds_nodes) : first < sc.n_lds_prims;
+            if (in_lds) {
+                const LdsNodes q = lds + (is_node ? 7u * cur : sc.lds_prim_off + 3u * first);
+                const v4f a = q[0], b = q[1], c = q[2];
+                b0 = make_float4(a.x, a.y, a.z, a.w);
+                b1 = make_float4(b.x, b.y, b.z, b.w);
+                b2 = make_float4(c.x, c.y, c.z, c.w);
+                if (is_node) {
+                    const v4f e = q[3], f = q[4], g = q[5], h = q[6];
+                    b3 = make_float4(e.x, e.y, e.z, e.w);
+                    b4 = make_float4(f.x, f.y, f.z, f.w);
+                    b5 = make_float4(g.x, g.y, g.z, g.w);
+                    b6 = make_float4(h.x, h.y, h.z, h.w);
+                }
+            } else {
+                const float4* q = is_node ? ac.nodes + MPT_OT_NODE_STRIDE * (size_t)cur : sc.prims + 3u * (size_t)first;
+                b0 = q[0];
+                b1 = q[1];
+                b2 = q[2];
+                if (is_node) {
+                    b3 = q[3];
+                    b4 = q[4];
+                    b5 = q[5];
+                    b6 = q[6];
+                }
+            }
+        }
+        if (is_node) {
+            const uint4 ref = make_uint4(__float_as_uint(b6.x), __float_as_uint(b6.y), __float_as_uint(b6.z), __float_as_uint(b6.w));
+            const float lim = ot_cull_limit(T, ac);
+            uint32_t k0 = ot_box_key(r, b0.x, b1.x, b2.x, b3.x, b4.x, b5.x, ref.x, lim, 0u);
+            uint32_t k1 = ot_box_key(r, b0.y, b1.y, b2.y, b3.y, b4.y, b5.y, ref.y, lim, 1u);
+            uint32_t k2 = ot_box_key(r, b0.z, b1.z, b2.z, b3.z, b4.z, b5.z, ref.z, lim, 2u);
+            uint32_t k3 = ot_box_key(r, b0.w, b1.w, b2.w, b3.w, b4.w, b5.w, ref.w, lim, 3u);
+            if (COUNT) {
+                wc.node_visits++;
+                wc.aabb_hits += (k0 < MPT_OT_KEY_MISS) + (k1 < MPT_OT_KEY_MISS) + (k2 < MPT_OT_KEY_MISS) + (k3 < MPT_OT_KEY_MISS);
+                if (first_active_lane()) wc.node_iters++;
+            }
+#ifdef MPT_OT_TIMES
+            if (first_active_lane()) wc.ot_node_trips++;
+            wc.ot_node_lanes++;
+#endif
+            ot_sort2(k0, k1);
+            ot_sort2(k2, k3);
+            ot_sort2(k0, k2);
+            ot_sort2(k1, k3);
+            ot_sort2(k1, k2);
+            if (k0 < MPT_OT_KEY_MISS) {
+                cur = ot_pick(ref, k0);
+                if (k1 < MPT_OT_KEY_MISS) ot_push_sorted(st, sp, ref, k1, k2, k3, overflow);
+            } else {
+                cur = ot_pop_next(st, sp, lim);
+            }
+        } else if (is_leaf) {
+            Prim3 pr;
+            pr.p0 = b0;
+            pr.p1 = b1;
+            pr.p2 = b2;
+            if (COUNT && first_active_lane()) wc.prim_iters++;
+#ifdef MPT_OT_TIMES
+            if (first_active_lane()) wc.ot_leaf_trips++;
+            wc.ot_leaf_lanes++;
+#endif
+            if (!(ac.n_always != 0u && prim_type(pr.p0) == 0)) {   // spheres are on the always list
+                if (COUNT) wc.prim_tests++;
+                ot_test_prim(pr, first, o, d, T, W, tie);
+            }
+            const uint32_t left = (cur >> 27) & 15u;   // primitives of the leaf behind this one
+            cur = left != 0u ? (MPT_OT_LEAF | ((left - 1u) << 27) | (first + 1u)) : ot_pop_next(st, sp, ot_cull_limit(T, ac));
+        }
+    }
+    return cur == MPT_OT_DONE;
+}
+
+#endif
+
+// ---- two primitives per leaf trip (was in ot_walk's leaf phase under MPT_OT_LEAF2) ----------------------------------------
+#if 0
+   // two primitives per trip: both records are requested before either is tested (leaves hold <= 2
+                      // primitives with the product's builders: one memory round trip per leaf instead of two)
+            for (uint32_t k = 0; k < count; k += 2u) {
+                const bool two = k + 1u < count;
+                const Prim3 pa = load_prim(sc, lds, first + k);
+                Prim3 pb = pa;
+                if (two) pb = load_prim(sc, lds, first + k + 1u);
+                if (COUNT && first_active_lane()) wc.prim_iters++;
+                if (!(ac.n_always != 0u && prim_type(pa.p0) == 0)) {
+                    if (COUNT) wc.prim_tests++;
+                    ot_test_prim(pa, first + k, o, d, T, W, tie);
+                }
+                if (two && !(ac.n_always != 0u && prim_type(pb.p0) == 0)) {
+                    if (COUNT) wc.prim_tests++;
+                    ot_test_prim(pb, first + k + 1u, o, d, T, W, tie);
+                }
+            }
+#endif

@@ -29,7 +29,9 @@ kinds = ["ring R (fresh rays)", "ring E (reference order)", "ring M0 (tree walk)
 for k in range(5):
     if v[8 + k]:
         print("  steps %-26s %10d  lanes/step %.1f" % (kinds[k], v[8 + k], v[16 + k] / v[8 + k]))
-w = v[24:29]
+w = v[24:31]
+if w[2]:
+    print("  walk lane utilisation: node loop %.1f %%, leaf loop %.1f %%" % (100.0 * w[5] / (64.0 * w[2]), 100.0 * w[6] / (64.0 * max(1, w[3]))))
 if w[2]:
     print("  walk: node loop %.1f %% of the walk cycles, %.0f cycles per wave trip (%d trips); leaf loop %.0f cycles per wave trip (%d trips); %d rounds"
           % (100.0 * w[0] / max(1, w[0] + w[1]), w[0] / w[2], w[2], w[1] / max(1, w[3]), w[3], w[4]))
