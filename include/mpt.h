@@ -67,12 +67,25 @@ enum { MPT_PIPE_WAVEFRONT = 0,  /* global SoA ray queues + wave64 ballot compact
                                    the BVH in the reference's own order (PathTracing.h:188-193)                      */
        MPT_PIPE_ORDERED = 3,    /* the same wave-local wavefront over the product's own 4-wide BVH, closest child
                                    first, with the reference-order walk for the rays whose answer could depend on the
-                                   order (same image bit for bit; falls back to pipeline 2 when a scene's child boxes
-                                   are not nested in their parents' or it has more than 16 spheres)                  */
+                                   order (falls back to pipeline 2 when a scene's child boxes are not nested in their
+                                   parents' or it has more than 16 spheres).  EXACTNESS: it returns the reference's closest
+                                   hit for every ray EXCEPT where the reference's own answer is an artefact of its float
+                                   arithmetic: a triangle accepted at a computed t that lies in FRONT of the triangle's
+                                   bounding box by more than t * 2^-10 — possible only when the ray lies within about
+                                   1e-5 / |e1 x e2| radians of the triangle's plane, so that |det| is just above the 1e-5
+                                   of PathTracing.h:153 and t = f * dot(e2, q) has lost its digits.  The closest-first
+                                   walk culls the box of such a triangle by distance and never computes that t; the
+                                   reference does if it happens to visit the leaf first.  Measured: 0 such rays in 1.3e11
+                                   rays of rendering (scene.xml, bunny x20, height fields, Cornell); 6e-6 of the rays
+                                   AIMED along the planes of 1..30-unit slivers (tests/test_gpu_adversarial.py, which
+                                   checks in exact arithmetic that every difference is of this kind).  No affordable
+                                   rule closes the gap: pipelines 0-2 reproduce the artefacts too.        */
        MPT_PIPE_AUTO = 4 };     /* pipeline 3 for scenes of MPT_AUTO_ORDERED_PRIMS (8192) primitives or more — where it
                                    is 1.5-2.2x faster — and pipeline 2 below that (scene.xml: pipeline 2 leads by a few
-                                   per cent since its box-test loop was rewritten for the scalar unit).  mpt_accel_info
-                                   out[7] tells which of the two AUTO stands for with the uploaded scene.               */
+                                   per cent since its box-test loop was rewritten for the scalar unit) and ALWAYS with
+                                   MPT_RNG_LITERAL, the mode that exists to reproduce the reference's frames.
+                                   mpt_accel_info out[7] tells which of the two AUTO stands for (philox) with the
+                                   uploaded scene.                                                                     */
 #define MPT_AUTO_ORDERED_PRIMS 8192u
 
 typedef struct mpt_render_params {

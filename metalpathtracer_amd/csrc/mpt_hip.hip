@@ -986,8 +986,11 @@ static inline bool count_flag(const mpt_render_params* p) { return (p->flags & M
 
 // the closest-first pipeline needs nested boxes and few spheres (mpt_upload_scene); otherwise the reference-order
 // wave-local pipeline renders the same image
-static int resolve_pipeline(const mpt_ctx* ctx, int pipeline) {
-    if (pipeline == MPT_PIPE_AUTO) pipeline = ctx->n_prims >= MPT_AUTO_ORDERED_PRIMS ? MPT_PIPE_ORDERED : MPT_PIPE_WAVELOCAL;
+// MPT_PIPE_AUTO never picks the closest-first pipeline for the literal RNG: that mode exists to reproduce the reference's
+// frames, arithmetic artefacts included, and only the reference's own visit order does that for every ray (include/mpt.h).
+static int resolve_pipeline(const mpt_ctx* ctx, int pipeline, int rng_mode = MPT_RNG_PHILOX) {
+    if (pipeline == MPT_PIPE_AUTO)
+        pipeline = ctx->n_prims >= MPT_AUTO_ORDERED_PRIMS && rng_mode != MPT_RNG_LITERAL ? MPT_PIPE_ORDERED : MPT_PIPE_WAVELOCAL;
     if (pipeline == MPT_PIPE_ORDERED && !ctx->acc_ok) pipeline = MPT_PIPE_WAVELOCAL;
     return pipeline;
 }
@@ -1011,7 +1014,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     if (rc) return rc;
     if (p->rng_mode == MPT_RNG_LITERAL && (rc = ensure_pixel_seeds(ctx))) return rc;
 
-    const int pipeline = resolve_pipeline(ctx, p->pipeline);
+    const int pipeline = resolve_pipeline(ctx, p->pipeline, p->rng_mode);
     pp.scene = scene_dev(ctx);
     pp.q[0] = L.q[0];
     pp.q[1] = L.q[1];
