@@ -216,6 +216,17 @@ int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims, float* bvh_out, uint64_t bvh_capacity_nodes,
                   uint64_t* n_nodes_out, int32_t* prim_idx_out, double* device_ms_out);
 
+/* Build -> render without the host: the same linear BVH, built on the device from the caller's primitive and material arrays
+ * (prims: 3 float4 each as Scene::createTransformsBuffer returns them, mats: 2 float4 each as Scene::createMaterialsBuffer)
+ * and turned ON THE DEVICE into everything mpt_upload_scene derives on the host — the threaded reference-order tree, the
+ * leaf-ordered primitive records, the de-duplicated materials, the product's own 4-wide tree — so that the scene is ready
+ * to render when the call returns (1 M primitives: tens of milliseconds; mpt_build_bvh + mpt_upload_scene: 0.55 s).  Stands
+ * for Scene::buildBVH + the four packers + Renderer::updateVisibleScene / buildBuffers (R/Scene/Scene.h:71-93,99-167,195-317,
+ * R/Renderer/Renderer.cpp:127-146,199-215).  mpt_download_bvh returns that tree in the REFERENCE's buffer format (as
+ * mpt_build_bvh does): what the reference's shader — and the oracle — would walk to produce the same image.                 */
+int mpt_build_and_upload(mpt_ctx* ctx, const float* prims, const float* mats, uint64_t n_prims, double* device_ms_out);
+int mpt_download_bvh(mpt_ctx* ctx, float* bvh_out, uint64_t bvh_capacity_nodes, uint64_t* n_nodes_out, int32_t* prim_idx_out);
+
 /* ---- multi-GPU: tile shards + ONE RCCL reduce of the HDR sum over xGMI ---------------------------------
  * The reference is single-GPU (it presents straight to the drawable, R/Renderer/Renderer.cpp:303-307); this is the
  * product's extension.  Every GPU renders the 8x8 pixel tiles t % N == rank (mpt_render_params.shard_rank / shard_count)

@@ -27,7 +27,7 @@ SYMBOLS = (
     "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
     "mpt_read_frame", "mpt_read_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
     "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
-    "mpt_build_bvh", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
+    "mpt_build_bvh", "mpt_build_and_upload", "mpt_download_bvh", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
     "mpt_comm_last_error",
 )
 
@@ -146,6 +146,8 @@ def load():
     L.mpt_trace_rays_ordered.argtypes = [vp, fp, fp, C.c_uint64, fp, ip, fp, ip, up]
     L.mpt_accel_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.mpt_build_bvh.argtypes = [vp, fp, C.c_uint64, fp, C.c_uint64, C.POINTER(C.c_uint64), ip, C.POINTER(C.c_double)]
+    L.mpt_build_and_upload.argtypes = [vp, fp, fp, C.c_uint64, C.POINTER(C.c_double)]
+    L.mpt_download_bvh.argtypes = [vp, fp, C.c_uint64, C.POINTER(C.c_uint64), ip]
     L.mpt_comm_unique_id.argtypes = [vp]
     L.mpt_comm_create_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
     L.mpt_comm_create_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
@@ -358,6 +360,25 @@ class Context:
         self._chk(self.L.mpt_build_bvh(self.h, _fp(prims), n, _fp(bvh), 2 * n - 1, C.byref(nn), _ip(idx), C.byref(ms)),
                   "mpt_build_bvh")
         return bvh[: nn.value].copy(), idx, ms.value
+
+    def build_and_upload(self, prims, mats):
+        """Build the BVH on the device and make it the scene, without a host round trip.  Returns the device ms."""
+        prims = np.ascontiguousarray(prims, np.float32).reshape(-1, 12)
+        mats = np.ascontiguousarray(mats, np.float32).reshape(-1, 8)
+        assert prims.shape[0] == mats.shape[0]
+        ms = C.c_double()
+        self._chk(self.L.mpt_build_and_upload(self.h, _fp(prims), _fp(mats), prims.shape[0], C.byref(ms)), "mpt_build_and_upload")
+        self._n_built = prims.shape[0]
+        return ms.value
+
+    def download_bvh(self):
+        """The tree of the last build_and_upload in the reference's buffer format: (bvh [N, 2, 4] f32, prim_idx [P] i32)."""
+        n = self._n_built
+        bvh = np.zeros((2 * n - 1, 2, 4), np.float32)
+        idx = np.zeros(n, np.int32)
+        nn = C.c_uint64()
+        self._chk(self.L.mpt_download_bvh(self.h, _fp(bvh), 2 * n - 1, C.byref(nn), _ip(idx)), "mpt_download_bvh")
+        return bvh[: nn.value].copy(), idx
 
     def accel_info(self):
         out = (C.c_uint64 * 8)()

@@ -99,7 +99,14 @@ void Renderer::updateVisibleScene() {
     const Scene::BuildMode mode = want == BUILD_BINNED ? Scene::BuildMode::BinnedCentroid
                                   : want == BUILD_GPU  ? Scene::BuildMode::GpuLbvh
                                                        : Scene::BuildMode::ReferenceSweep;
-    std::printf("BVH builder: %s\n", want == BUILD_BINNED ? "binned SAH (host)" : want == BUILD_GPU ? "linear BVH (device)" : "reference sweep SAH");
+    std::printf("BVH builder: %s\n", want == BUILD_BINNED ? "binned SAH (host)" : want == BUILD_GPU ? "linear BVH (device, build -> render without the host)" : "reference sweep SAH");
+    deviceBuild_ = want == BUILD_GPU;
+    if (deviceBuild_) {   // mpt_build_and_upload in buildBuffers(): the tree never exists on the host
+        scene_->sortPrimitives();
+        deviceDirty_ = true;
+        buildBuffers();
+        return;
+    }
     scene_->buildBVH(mode);
     std::printf("BVH node count: %zu\n", scene_->getBVHNodeCount());
     buildBuffers();
@@ -114,6 +121,25 @@ void Renderer::buildBuffers() {
     // (R/Renderer/Renderer.cpp:127-146,199-215); the device layout needs all four at once, so one upload.
     const size_t P = scene_->getPrimitiveCount();
     sceneUploaded_ = false;
+    if (deviceBuild_) {
+        if (!deviceDirty_) {   // (the constructor calls buildBuffers() once more after updateVisibleScene(), as the reference's does)
+            sceneUploaded_ = P != 0;
+            return;
+        }
+        deviceDirty_ = false;
+        if (P == 0) return;
+        mpt::float4* prims = scene_->createTransformsBuffer();
+        mpt::float4* mats = scene_->createMaterialsBuffer();
+        double ms = 0.0;
+        int rc = mpt_build_and_upload(ctx_, reinterpret_cast<const float*>(prims), reinterpret_cast<const float*>(mats), P, &ms);
+        delete[] prims;
+        delete[] mats;
+        check(rc, "mpt_build_and_upload");
+        std::printf("BVH built on the device in %.2f ms\n", ms);
+        sceneUploaded_ = true;
+        std::memset(&uniforms_, 0, sizeof uniforms_);
+        return;
+    }
     if (P == 0 || scene_->getBVHNodeCount() == 0) return;
     mpt::float4* bvh = scene_->createBVHBuffer();
     mpt::float4* prims = scene_->createTransformsBuffer();

@@ -71,6 +71,7 @@ private:
     uint32_t hostSeed_ = 92407235u;  // R/Renderer/Renderer.cpp:32
     bool sceneUploaded_ = false;
     int buildMode_ = BUILD_REFERENCE;
+    bool deviceBuild_ = false, deviceDirty_ = false;   // BUILD_GPU: mpt_build_and_upload, no tree on the host
 };
 
 }  // namespace MetalCppPathTracer

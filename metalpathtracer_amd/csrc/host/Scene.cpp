@@ -283,12 +283,29 @@ size_t Scene::getTriangleCount() const {
 
 void Scene::buildBVH() { buildBVH(BuildMode::ReferenceSweep); }
 
-void Scene::buildBVH(BuildMode mode) {
+void Scene::sortPrimitives() {
     // spheres before triangles, original order kept inside each class: primitive ids are the positions
     // after this sort (R/Scene/Scene.h:72-75)
     std::stable_sort(primitives_.begin(), primitives_.end(), [](const Primitive& a, const Primitive& b) {
         return static_cast<int>(a.type) < static_cast<int>(b.type);
     });
+}
+
+void Scene::adoptBVH(const float* bvh, size_t nodeCount, const int32_t* primIdx) {
+    nodes_.resize(nodeCount);
+    for (size_t i = 0; i < nodeCount; ++i) {
+        const float* q = bvh + 8 * i;
+        nodes_[i].boundsMin = float3(q[0], q[1], q[2]);
+        nodes_[i].boundsMax = float3(q[4], q[5], q[6]);
+        std::memcpy(&nodes_[i].leftFirst, q + 3, 4);
+        std::memcpy(&nodes_[i].count, q + 7, 4);
+    }
+    primitiveIndices_.resize(primitives_.size());
+    for (size_t i = 0; i < primitiveIndices_.size(); ++i) primitiveIndices_[i] = static_cast<size_t>(primIdx[i]);
+}
+
+void Scene::buildBVH(BuildMode mode) {
+    sortPrimitives();
     primitiveIndices_.resize(primitives_.size());
     for (size_t i = 0; i < primitiveIndices_.size(); ++i) primitiveIndices_[i] = i;
     nodes_.clear();
@@ -337,15 +354,7 @@ void Scene::buildOnGpu() {
     mpt_destroy(ctx);
     if (rc != MPT_OK) throw std::runtime_error("Scene::buildBVH(GpuLbvh): " + err);
     lastGpuBuildMs_ = ms;
-    nodes_.resize(nn);
-    for (size_t i = 0; i < nn; ++i) {
-        const float* q = bvh.data() + 8 * i;
-        nodes_[i].boundsMin = float3(q[0], q[1], q[2]);
-        nodes_[i].boundsMax = float3(q[4], q[5], q[6]);
-        std::memcpy(&nodes_[i].leftFirst, q + 3, 4);
-        std::memcpy(&nodes_[i].count, q + 7, 4);
-    }
-    for (size_t i = 0; i < n; ++i) primitiveIndices_[i] = static_cast<size_t>(idx[i]);
+    adoptBVH(bvh.data(), nn, idx.data());
 }
 
 int Scene::getBVHDepth() const {

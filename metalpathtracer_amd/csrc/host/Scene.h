@@ -51,12 +51,16 @@ public:
     const std::vector<size_t>& getPrimitiveIndices() const { return primitiveIndices_; }
     const std::vector<Primitive>& getPrimitives() const { return primitives_; }
 
+    void sortPrimitives();           // spheres before triangles, stable: the first thing buildBVH does (R/Scene/Scene.h:72-75)
     void buildBVH();                 // reference-compatible tree
     void buildBVH(BuildMode mode);
     size_t getBVHNodeCount() const { return nodes_.size(); }
     const std::vector<BVHNode>& getBVHNodes() const { return nodes_; }
     int getBVHDepth() const;
     double lastGpuBuildMs() const { return lastGpuBuildMs_; }   // HIP-event time of the last GpuLbvh build
+    // takes a tree in the reference's buffer format (8 floats per node, one int per primitive): what mpt_build_bvh and
+    // mpt_download_bvh return
+    void adoptBVH(const float* bvh, size_t nodeCount, const int32_t* primIdx);
 
     // Flat buffers in the layout the hot path consumes.  Caller owns the arrays (delete[]).
     mpt::float4* createTransformsBuffer() const;       // 3 float4 / primitive

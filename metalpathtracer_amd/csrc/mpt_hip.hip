@@ -26,6 +26,7 @@
 
 #include "mpt_kernels.h"
 #include "mpt_lbvh.h"
+#include "mpt_devbuild.h"
 #include "mpt_ordered.h"
 
 // =====================================================================================================
@@ -105,6 +106,10 @@ struct mpt_ctx {
     float4* d_refleaf = nullptr;
     float4* d_always = nullptr;
     uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, ot_lds_nodes = 0, ot_lds_prims = 0;
+    // mpt_build_and_upload keeps its tree in the reference's buffer format on the device too (mpt_download_bvh)
+    float4* d_ref_bvh = nullptr;
+    int* d_ref_idx = nullptr;
+    uint32_t n_ref_nodes = 0;
     uint32_t ot_stack_depth = 8;     // LDS stack entries per lane (MPT_OT_STACK); deeper entries spill to global memory
     OtBudgets ot_budgets = default_ot_budgets();
     float tri_extent = 0.0f, acc_eps_abs = 0.0f, acc_cull_rel = 9.765625e-4f;
@@ -330,6 +335,8 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_acc_nodes);
     hipFree(ctx->d_refleaf);
     hipFree(ctx->d_always);
+    hipFree(ctx->d_ref_bvh);
+    hipFree(ctx->d_ref_idx);
     hipFree(ctx->d_accum[0]);
     hipFree(ctx->d_accum[1]);
     hipFree(ctx->d_sum_own);
@@ -376,6 +383,37 @@ static inline float int_to_bits(int i) {
     return f;
 }
 }  // namespace
+
+// What each kernel stages in LDS, from the sizes of the uploaded scene.
+static void size_lds_images(mpt_ctx* ctx) {
+    // LDS image of the reference-order kernels = top of the tree + primitives of the shallowest leaves.  When the whole
+    // tree fits, the rest of the budget goes to primitives; otherwise 6 KiB are reserved for them (the leaves next to the
+    // root are visited by almost every ray: on scene.xml the three spheres take 65 % of all primitive tests).
+    {
+        const size_t budget = ctx->lds_budget > MPT_LDS_EXTRA ? ctx->lds_budget - MPT_LDS_EXTRA : 0;
+        const size_t all_nodes = (size_t)ctx->n_nodes * 32, all_prims = (size_t)ctx->n_prims * 48;
+        size_t prim_bytes = all_nodes <= budget ? std::min(all_prims, budget - all_nodes)
+                                                : std::min<size_t>(all_prims, std::min<size_t>(6 * 1024, budget / 4));
+        prim_bytes -= prim_bytes % 48;
+        ctx->n_lds_prims = (uint32_t)(prim_bytes / 48);
+        ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, (budget - prim_bytes) / 32);
+    }
+    // LDS image of the closest-first kernel (MPT_OT_WGS_PER_CU workgroups of MPT_OT_THREADS share a CU's 160 KiB): the
+    // stacks, then as many own nodes as fit (breadth-first prefix), the always list, and primitives with what is left.
+    {
+        const size_t stacks = (size_t)MPT_OT_THREADS * ctx->ot_stack_depth * 8;
+        // (two workgroups per CU get 78 KiB each, not 80: the allocation granule must leave both room)
+        const size_t avail = MPT_OT_WGS_PER_CU == 1 ? 160 * 1024 : 156 * 1024 / MPT_OT_WGS_PER_CU, fixed = MPT_LDS_EXTRA + stacks + (size_t)ctx->n_always * 80;
+        const size_t total = avail > fixed + 112 ? avail - fixed : 112;
+        const size_t all_nodes = (size_t)ctx->n_acc_nodes * 112, all_prims = (size_t)ctx->n_prims * 48;
+        size_t prim_bytes = all_nodes <= total ? std::min(all_prims, total - all_nodes)
+                                               : std::min<size_t>(all_prims, std::min<size_t>(4 * 1024, total / 4));
+        prim_bytes -= prim_bytes % 48;
+        ctx->ot_lds_prims = (uint32_t)(prim_bytes / 48);
+        if (const char* e = getenv("MPT_OT_LDS_PRIMS")) ctx->ot_lds_prims = std::min<uint32_t>(ctx->ot_lds_prims, (uint32_t)atoi(e));
+        ctx->ot_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
+    }
+}
 
 static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims,
                                 const float* mats, const int32_t* prim_idx, uint64_t n_prims) {
@@ -682,7 +720,11 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     hipFree(ctx->d_acc_nodes);
     hipFree(ctx->d_refleaf);
     hipFree(ctx->d_always);
-    ctx->d_nodes = ctx->d_prims = ctx->d_mats = ctx->d_acc_nodes = ctx->d_refleaf = ctx->d_always = nullptr;
+    hipFree(ctx->d_ref_bvh);
+    hipFree(ctx->d_ref_idx);
+    ctx->d_nodes = ctx->d_prims = ctx->d_mats = ctx->d_acc_nodes = ctx->d_refleaf = ctx->d_always = ctx->d_ref_bvh = nullptr;
+    ctx->d_ref_idx = nullptr;
+    ctx->n_ref_nodes = 0;
     ctx->have_scene = false;
     auto up = [&](float4** dst, const std::vector<float>& v, size_t min_floats) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max(v.size(), min_floats) * 4);
@@ -706,33 +748,7 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     ctx->acc_eps_abs = tri_extent * 3.814697265625e-06f;  // 2^-18 of the largest triangle coordinate
     ctx->acc_ok = nested && use_always;
     ctx->acc_why = !nested ? "a child box is not inside its parent's box" : !use_always ? "more than 16 spheres" : "";
-    // LDS image of the reference-order kernels = top of the tree + primitives of the shallowest leaves.  When the whole
-    // tree fits, the rest of the budget goes to primitives; otherwise 6 KiB are reserved for them (the leaves next to the
-    // root are visited by almost every ray: on scene.xml the three spheres take 65 % of all primitive tests).
-    {
-        const size_t budget = ctx->lds_budget > MPT_LDS_EXTRA ? ctx->lds_budget - MPT_LDS_EXTRA : 0;
-        const size_t all_nodes = (size_t)ND * 32, all_prims = dprims.size() / 12 * 48;
-        size_t prim_bytes = all_nodes <= budget ? std::min(all_prims, budget - all_nodes)
-                                                : std::min<size_t>(all_prims, std::min<size_t>(6 * 1024, budget / 4));
-        prim_bytes -= prim_bytes % 48;
-        ctx->n_lds_prims = (uint32_t)(prim_bytes / 48);
-        ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ND, (budget - prim_bytes) / 32);
-    }
-    // LDS image of the closest-first kernel (MPT_OT_WGS_PER_CU workgroups of MPT_OT_THREADS share a CU's 160 KiB): the
-    // stacks, then as many own nodes as fit (breadth-first prefix), the always list, and primitives with what is left.
-    {
-        const size_t stacks = (size_t)MPT_OT_THREADS * ctx->ot_stack_depth * 8;
-        // (two workgroups per CU get 78 KiB each, not 80: the allocation granule must leave both room)
-        const size_t avail = MPT_OT_WGS_PER_CU == 1 ? 160 * 1024 : 156 * 1024 / MPT_OT_WGS_PER_CU, fixed = MPT_LDS_EXTRA + stacks + (size_t)ctx->n_always * 80;
-        const size_t total = avail > fixed + 112 ? avail - fixed : 112;
-        const size_t all_nodes = (size_t)ctx->n_acc_nodes * 112, all_prims = (size_t)ctx->n_prims * 48;
-        size_t prim_bytes = all_nodes <= total ? std::min(all_prims, total - all_nodes)
-                                               : std::min<size_t>(all_prims, std::min<size_t>(4 * 1024, total / 4));
-        prim_bytes -= prim_bytes % 48;
-        ctx->ot_lds_prims = (uint32_t)(prim_bytes / 48);
-        if (const char* e = getenv("MPT_OT_LDS_PRIMS")) ctx->ot_lds_prims = std::min<uint32_t>(ctx->ot_lds_prims, (uint32_t)atoi(e));
-        ctx->ot_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
-    }
+    size_lds_images(ctx);
     ctx->have_scene = true;
     return MPT_OK;
 }
@@ -1501,6 +1517,94 @@ static int kat_sincos_impl(mpt_ctx* ctx, const float* u, uint64_t n, float* s, f
 }
 
 
+// ---- build -> render without the host (mpt_devbuild.h) -------------------------------------------------------------------------
+static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* mats, uint64_t n_prims, double* device_ms_out) {
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    if (!prims || !mats || n_prims == 0) return fail(ctx, MPT_ERR_INVALID_ARG, "null or empty primitive / material array");
+    if (n_prims >= (1ull << 27)) return fail(ctx, MPT_ERR_BAD_SCENE, "scene too large for the 27-bit leaf encoding");
+    {
+        int wrc = wait_impl(ctx);  // renders in flight still read the old scene
+        if (wrc) return wrc;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = (uint32_t)n_prims;
+    uint32_t n_spheres = 0;   // (whether the always list can be used decides the own boxes of the leaves that hold spheres)
+    for (uint32_t i = 0; i < n; ++i) n_spheres += (int)prims[12 * (size_t)i + 3] != 1 ? 1u : 0u;
+    DevBuf d_p, d_m;
+    HIPCHK(d_p.alloc((size_t)n * 48));
+    HIPCHK(d_m.alloc((size_t)n * 32));
+    HIPCHK(hipMemcpyAsync(d_p.p, prims, (size_t)n * 48, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_m.p, mats, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int leaf_max = 2;
+    if (const char* lm = getenv("MPT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        hipEventDestroy(e0);
+        return fail(ctx, MPT_ERR_HIP, "hipEventCreate failed");
+    }
+    hipEventRecord(e0, ctx->stream);
+    mpt_devbuild::Built b;
+    hipError_t e = mpt_devbuild::build(ctx->stream, (float4*)d_p.p, (const float4*)d_m.p, n, leaf_max, n_spheres, b);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (e != hipSuccess) {
+        b.release();
+        return fail(ctx, MPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
+    }
+    if (b.n_spheres != n_spheres) {
+        b.release();
+        return fail(ctx, MPT_ERR_HIP, "GPU BVH build: sphere count mismatch (internal)");
+    }
+    hipFree(ctx->d_nodes);
+    hipFree(ctx->d_prims);
+    hipFree(ctx->d_mats);
+    hipFree(ctx->d_acc_nodes);
+    hipFree(ctx->d_refleaf);
+    hipFree(ctx->d_always);
+    hipFree(ctx->d_ref_bvh);
+    hipFree(ctx->d_ref_idx);
+    ctx->d_nodes = b.nodes;
+    ctx->d_prims = b.prims;
+    ctx->d_mats = b.mats;
+    ctx->d_acc_nodes = b.acc_nodes;
+    ctx->d_refleaf = b.refleaf;
+    ctx->d_always = b.always;
+    ctx->d_ref_bvh = b.ref_bvh;
+    ctx->d_ref_idx = b.ref_idx;
+    ctx->n_ref_nodes = b.n_nodes;
+    ctx->n_nodes = b.n_nodes;
+    ctx->n_prims = b.n_prims;
+    ctx->n_mats = b.n_mats;
+    ctx->n_acc_nodes = b.n_acc_nodes;
+    ctx->n_always = b.n_always;
+    ctx->n_ref_leaves = b.n_ref_leaves;
+    ctx->acc_depth = b.acc_depth;
+    ctx->tri_extent = b.tri_extent;
+    ctx->acc_eps_abs = b.tri_extent * 3.814697265625e-06f;  // 2^-18 of the largest triangle coordinate
+    ctx->acc_ok = n_spheres <= MPT_ACCEL_MAX_ALWAYS;        // (parent boxes are unions of child boxes: nested by construction)
+    ctx->acc_why = ctx->acc_ok ? "" : "more than 16 spheres";
+    size_lds_images(ctx);
+    ctx->have_scene = true;
+    if (device_ms_out) *device_ms_out = ms;
+    return MPT_OK;
+}
+
+static int download_bvh_impl(mpt_ctx* ctx, float* bvh_out, uint64_t cap_nodes, uint64_t* n_nodes_out, int32_t* prim_idx_out) {
+    if (!ctx || !bvh_out || !n_nodes_out || !prim_idx_out) return fail(ctx, MPT_ERR_INVALID_ARG, "bad argument");
+    if (!ctx->have_scene || !ctx->d_ref_bvh) return fail(ctx, MPT_ERR_NOT_READY, "the scene was not built by mpt_build_and_upload");
+    if (cap_nodes < ctx->n_ref_nodes) return fail(ctx, MPT_ERR_INVALID_ARG, "bvh_out too small");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpy(bvh_out, ctx->d_ref_bvh, (size_t)ctx->n_ref_nodes * 32, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(prim_idx_out, ctx->d_ref_idx, (size_t)ctx->n_prims * 4, hipMemcpyDeviceToHost));
+    *n_nodes_out = ctx->n_ref_nodes;
+    return MPT_OK;
+}
+
 // ---- exception barrier: nothing thrown by the host-side containers may cross the C ABI (include/mpt.h) --------
 template <class F>
 static int guarded(mpt_ctx* ctx, F&& body) noexcept {
@@ -1593,6 +1697,14 @@ extern "C" int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims,
         if (device_ms_out) *device_ms_out = ms;
         return MPT_OK;
     });
+}
+
+extern "C" int mpt_build_and_upload(mpt_ctx* ctx, const float* prims, const float* mats, uint64_t n_prims, double* device_ms_out) {
+    return guarded(ctx, [&] { return build_and_upload_impl(ctx, prims, mats, n_prims, device_ms_out); });
+}
+
+extern "C" int mpt_download_bvh(mpt_ctx* ctx, float* bvh_out, uint64_t bvh_capacity_nodes, uint64_t* n_nodes_out, int32_t* prim_idx_out) {
+    return guarded(ctx, [&] { return download_bvh_impl(ctx, bvh_out, bvh_capacity_nodes, n_nodes_out, prim_idx_out); });
 }
 
 extern "C" int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* h, float* f) {

@@ -201,40 +201,105 @@ struct Scratch {  // freed on every exit path
     }
 };
 
-// prims: host, 12 floats per primitive (Scene::createTransformsBuffer).  bvh_out: host, room for 8 * (2n - 1) floats;
-// prim_idx_out: host, n ints.  Returns hipSuccess and the node count, or the failing HIP status.
-static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int leaf_max, float* bvh_out, uint64_t* n_nodes_out,
-                        int32_t* prim_idx_out, float* ms_out) {
 #define MPT_LB(call)                       \
     do {                                   \
         hipError_t e_ = (call);            \
         if (e_ != hipSuccess) return e_;   \
     } while (0)
-    Scratch sc;
-    float4 *d_prims, *blo, *bhi, *nlo, *nhi, *d_bvh;
-    int *cb, *parent, *arrived, *d_idx;
-    int2 *child, *range;
+
+// The radix tree as it stands on the device after build_radix (all arrays owned by the Scratch passed in):
+//   node ids: internal k in [0, n-1), single primitive at sorted position p -> (n-1) + p;  2n - 1 ids in all
+//   an OUTPUT node is one with keep[id] != 0: internal nodes spanning more than leaf_max primitives, and the nodes below
+//   them spanning <= leaf_max (the leaves: primitives [first, first + count) of the SORTED order, vals[] = original ids)
+struct Radix {
+    uint32_t n = 0;
+    int leaf_max = 2;
+    float4 *prims = nullptr;             // the caller's primitive array (3 float4 each), on the device
+    float4 *blo = nullptr, *bhi = nullptr;   // primitive boxes (original order)
+    float4 *nlo = nullptr, *nhi = nullptr;   // node boxes by id
+    int2 *child = nullptr, *range = nullptr; // internal nodes
+    int *parent = nullptr;                   // by id (-1 at the root)
+    uint32_t *vals = nullptr;                // sorted position -> original primitive
+    uint32_t *keep = nullptr, *index = nullptr;  // output flag / compact output index by id; index[2n-1] = number of output nodes
+    int *cb = nullptr;                       // centroid bounds (ordered ints)
+    uint32_t n_out = 0;                      // output nodes (read back)
+};
+
+// d_prims: device, 3 float4 per primitive.  Leaves everything of Radix on the device; synchronises the stream once to
+// read the output node count.
+static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, uint32_t n, int leaf_max, Radix& R) {
+    int *arrived;
     unsigned long long *keys, *keys2;
-    uint32_t *vals, *vals2, *keep, *index;
+    uint32_t *vals0;
     const size_t nn = 2 * (size_t)n - 1;
-    MPT_LB(sc.alloc(&d_prims, 3 * (size_t)n));
-    MPT_LB(sc.alloc(&blo, n));
-    MPT_LB(sc.alloc(&bhi, n));
-    MPT_LB(sc.alloc(&nlo, nn));
-    MPT_LB(sc.alloc(&nhi, nn));
-    MPT_LB(sc.alloc(&d_bvh, 2 * nn));
-    MPT_LB(sc.alloc(&cb, 6));
-    MPT_LB(sc.alloc(&parent, nn));
+    R.n = n;
+    R.leaf_max = leaf_max;
+    R.prims = d_prims;
+    MPT_LB(sc.alloc(&R.blo, n));
+    MPT_LB(sc.alloc(&R.bhi, n));
+    MPT_LB(sc.alloc(&R.nlo, nn));
+    MPT_LB(sc.alloc(&R.nhi, nn));
+    MPT_LB(sc.alloc(&R.cb, 6));
+    MPT_LB(sc.alloc(&R.parent, nn));
     MPT_LB(sc.alloc(&arrived, n));
-    MPT_LB(sc.alloc(&d_idx, n));
-    MPT_LB(sc.alloc(&child, n));
-    MPT_LB(sc.alloc(&range, n));
+    MPT_LB(sc.alloc(&R.child, n));
+    MPT_LB(sc.alloc(&R.range, n));
     MPT_LB(sc.alloc(&keys, n));
     MPT_LB(sc.alloc(&keys2, n));
-    MPT_LB(sc.alloc(&vals, n));
-    MPT_LB(sc.alloc(&vals2, n));
-    MPT_LB(sc.alloc(&keep, nn + 1));
-    MPT_LB(sc.alloc(&index, nn + 1));
+    MPT_LB(sc.alloc(&vals0, n));
+    MPT_LB(sc.alloc(&R.vals, n));
+    MPT_LB(sc.alloc(&R.keep, nn + 1));
+    MPT_LB(sc.alloc(&R.index, nn + 1));
+    const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    MPT_LB(hipMemcpyAsync(R.cb, init, sizeof init, hipMemcpyHostToDevice, stream));
+    MPT_LB(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
+    const uint32_t B = 256, gn = (n + B - 1) / B, gnn = (uint32_t)((nn + B - 1) / B);
+    hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, R.blo, R.bhi, R.cb);
+    hipLaunchKernelGGL(k_morton, dim3(gn), dim3(B), 0, stream, (const float4*)R.blo, (const float4*)R.bhi, n, (const int*)R.cb, keys, vals0);
+    size_t tmp_bytes = 0;
+    MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals0, R.vals, (int)n, 0, 63, stream));
+    char* tmp;
+    MPT_LB(sc.alloc(&tmp, tmp_bytes));
+    MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals0, R.vals, (int)n, 0, 63, stream));
+    if (n > 1) {
+        hipLaunchKernelGGL(k_hierarchy, dim3(gn), dim3(B), 0, stream, (const unsigned long long*)keys2, (int)n, R.child, R.parent, R.range);
+    } else {
+        const int minus1 = -1;
+        MPT_LB(hipMemcpyAsync(R.parent, &minus1, 4, hipMemcpyHostToDevice, stream));
+    }
+    hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, stream, (const uint32_t*)R.vals, (const float4*)R.blo, (const float4*)R.bhi, (int)n,
+                       (const int2*)R.child, (const int*)R.parent, R.nlo, R.nhi, arrived);
+    hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int*)R.parent, (const int2*)R.range, R.keep);
+    size_t scan_bytes = 0;
+    MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
+    char* tmp2;
+    MPT_LB(sc.alloc(&tmp2, scan_bytes));
+    MPT_LB(hipMemsetAsync(R.keep + nn, 0, 4, stream));
+    MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
+    MPT_LB(hipGetLastError());
+    MPT_LB(hipMemcpyAsync(&R.n_out, R.index + nn, 4, hipMemcpyDeviceToHost, stream));
+    MPT_LB(hipStreamSynchronize(stream));
+    return hipSuccess;
+}
+
+// the output tree in the reference's buffer format, on the device: d_bvh (2 float4 per output node), d_idx (n ints)
+static hipError_t emit_reference_format(hipStream_t stream, const Radix& R, float4* d_bvh, int* d_idx) {
+    const size_t nn = 2 * (size_t)R.n - 1;
+    hipLaunchKernelGGL(k_emit, dim3((uint32_t)((nn + 255) / 256)), dim3(256), 0, stream, (int)R.n, R.leaf_max, (const int2*)R.child, (const int2*)R.range,
+                       (const uint32_t*)R.keep, (const uint32_t*)R.index, (const float4*)R.nlo, (const float4*)R.nhi, (const uint32_t*)R.vals, d_bvh, d_idx);
+    return hipGetLastError();
+}
+
+// prims: host, 12 floats per primitive (Scene::createTransformsBuffer).  bvh_out: host, room for 8 * (2n - 1) floats;
+// prim_idx_out: host, n ints.  Returns hipSuccess and the node count, or the failing HIP status.
+static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int leaf_max, float* bvh_out, uint64_t* n_nodes_out,
+                        int32_t* prim_idx_out, float* ms_out) {
+    Scratch sc;
+    float4 *d_prims, *d_bvh;
+    int* d_idx;
+    MPT_LB(sc.alloc(&d_prims, 3 * (size_t)n));
+    MPT_LB(sc.alloc(&d_bvh, 2 * (2 * (size_t)n - 1)));
+    MPT_LB(sc.alloc(&d_idx, n));
     MPT_LB(hipMemcpyAsync(d_prims, prims, (size_t)n * 48, hipMemcpyHostToDevice, stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     MPT_LB(hipEventCreate(&e0));
@@ -244,43 +309,15 @@ static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int 
         return rc;
     }
     auto body = [&]() -> hipError_t {
-        const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-        MPT_LB(hipMemcpyAsync(cb, init, sizeof init, hipMemcpyHostToDevice, stream));
-        MPT_LB(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
         MPT_LB(hipEventRecord(e0, stream));
-        const uint32_t B = 256, gn = (n + B - 1) / B, gnn = (uint32_t)((nn + B - 1) / B);
-        hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, blo, bhi, cb);
-        hipLaunchKernelGGL(k_morton, dim3(gn), dim3(B), 0, stream, (const float4*)blo, (const float4*)bhi, n, (const int*)cb, keys, vals);
-        size_t tmp_bytes = 0;
-        MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, stream));
-        char* tmp;
-        MPT_LB(sc.alloc(&tmp, tmp_bytes));
-        MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, stream));
-        if (n > 1) {
-            hipLaunchKernelGGL(k_hierarchy, dim3(gn), dim3(B), 0, stream, (const unsigned long long*)keys2, (int)n, child, parent, range);
-        } else {
-            const int minus1 = -1;
-            MPT_LB(hipMemcpyAsync(parent, &minus1, 4, hipMemcpyHostToDevice, stream));
-        }
-        hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, stream, (const uint32_t*)vals2, (const float4*)blo, (const float4*)bhi, (int)n,
-                           (const int2*)child, (const int*)parent, nlo, nhi, arrived);
-        hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int*)parent, (const int2*)range, keep);
-        size_t scan_bytes = 0;
-        MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, index, (int)nn + 1, stream));
-        char* tmp2;
-        MPT_LB(sc.alloc(&tmp2, scan_bytes));
-        MPT_LB(hipMemsetAsync(keep + nn, 0, 4, stream));
-        MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, scan_bytes, keep, index, (int)nn + 1, stream));
-        hipLaunchKernelGGL(k_emit, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int2*)child, (const int2*)range, (const uint32_t*)keep,
-                           (const uint32_t*)index, (const float4*)nlo, (const float4*)nhi, (const uint32_t*)vals2, d_bvh, d_idx);
-        MPT_LB(hipGetLastError());
+        Radix R;
+        MPT_LB(build_radix(stream, sc, d_prims, n, leaf_max, R));
+        MPT_LB(emit_reference_format(stream, R, d_bvh, d_idx));
         MPT_LB(hipEventRecord(e1, stream));
-        uint32_t n_out = 0;
-        MPT_LB(hipMemcpyAsync(&n_out, index + nn, 4, hipMemcpyDeviceToHost, stream));
         MPT_LB(hipStreamSynchronize(stream));
-        MPT_LB(hipMemcpy(bvh_out, d_bvh, (size_t)n_out * 32, hipMemcpyDeviceToHost));
+        MPT_LB(hipMemcpy(bvh_out, d_bvh, (size_t)R.n_out * 32, hipMemcpyDeviceToHost));
         MPT_LB(hipMemcpy(prim_idx_out, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
-        *n_nodes_out = n_out;
+        *n_nodes_out = R.n_out;
         if (ms_out) MPT_LB(hipEventElapsedTime(ms_out, e0, e1));
         return hipSuccess;
     };
@@ -288,7 +325,6 @@ static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int 
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     return rc;
-#undef MPT_LB
 }
 
 }  // namespace mpt_lbvh

@@ -142,6 +142,15 @@ class Scene:
     def getBVHDepth(self):
         return self._counts()[3]
 
+    def packed_primitives(self):
+        """(prims [P,3,4], mats [P,2,4]) without a tree: what mpt_build_and_upload takes (createTransformsBuffer /
+        createMaterialsBuffer, R/Scene/Scene.h:99-133)."""
+        P = self._counts()[0]
+        prims = np.zeros((P, 3, 4), np.float32)
+        mats = np.zeros((P, 2, 4), np.float32)
+        self.L.mpt_scene_copy_buffers(self.h, None, _fp(prims), _fp(mats), None)
+        return prims, mats
+
     def buffers(self):
         """(bvh [N,2,4], prims [P,3,4], mats [P,2,4], prim_idx [P]) — createBVHBuffer / createTransformsBuffer /
         createMaterialsBuffer / createPrimitiveIndexBuffer (R/Scene/Scene.h:99-167)."""

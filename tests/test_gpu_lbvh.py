@@ -92,3 +92,122 @@ def test_gpu_build_small_inputs_and_determinism(gpu_ctx):
         np.testing.assert_array_equal(bvh.view(np.uint32), bvh2.view(np.uint32))
         np.testing.assert_array_equal(idx, idx2)
         assert (n <= 2) == (bvh.shape[0] == 1)                       # leaves hold <= 2 primitives by default
+
+
+@pytest.mark.parametrize("name,bsdf", [("scene.xml", 0), ("glass.xml", 1), ("bunny20.xml", 0), ("cornell.xml", 0)])
+def test_build_and_upload_renders_the_oracle_image_of_its_own_tree(gpu_ctx, name, bsdf):
+    """mpt_build_and_upload: build -> render without the host.  The tree it built comes back in the reference's format
+    (mpt_download_bvh); it must be well formed, and the oracle must render from it exactly what both HIP pipelines render
+    from the device-resident structures (threaded tree, own 4-wide tree, always list, materials: all derived on the device)."""
+    from metalpathtracer_amd import capi, host
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(scene_path(name), sc)
+    assert st == 0, log
+    sc.buildBVH()                                                  # (only to have the packed primitive / material arrays)
+    _, prims, mats, _ = sc.buffers()
+    ms = gpu_ctx.build_and_upload(prims, mats)
+    assert 0.0 < ms < 200.0
+    bvh, idx = gpu_ctx.download_bvh()
+    p12 = np.asarray(prims).reshape(-1, 12)
+    leaves, depth = _check_tree(bvh.reshape(-1, 8), idx, p12)
+    info = gpu_ctx.accel_info()
+    assert info["ordered_ok"] == 1 and info["reference_leaves"] == leaves and info["nodes"] >= 1
+    assert info["always_spheres"] == int((p12[:, 3] == 0).sum())
+    W, H, spp = 160, 90, 3
+    from conftest import CORNELL_CAM
+    u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=CORNELL_CAM if name == "cornell.xml" else None)
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_uniforms(u)
+    buffers = (bvh, prims, mats, idx)
+    ref, ct = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buffers, rng_mode=ob.RNG_PHILOX, bsdf_mode=bsdf, max_depth=8,
+                        accumulate=1, sample_count=spp, seed=(4, 2), threads=8)
+    for pipe in (capi.PIPE_ORDERED, capi.PIPE_WAVELOCAL, capi.PIPE_MEGAKERNEL):
+        gpu_ctx.clear_sum()
+        gpu_ctx.reset_stats()
+        gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=8, sample_count=spp, seed=(4, 2), pipeline=pipe,
+                       flags=capi.FLAG_COUNT_WORK)
+        np.testing.assert_array_equal(gpu_ctx.read_sum().view(np.uint32), ref.view(np.uint32))
+        st = gpu_ctx.stats()
+        assert st["rays"] == ct["rays"]
+        if pipe != capi.PIPE_ORDERED:                               # the reference-order walk does the oracle's work, test for test
+            assert (st["node_visits"], st["prim_tests"]) == (ct["node_pops"], ct["prim_tests"])
+    # the host route over the same arrays (mpt_upload_scene of the downloaded tree) renders the same image
+    gpu_ctx.upload_scene(*buffers)
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=8, sample_count=spp, seed=(4, 2))
+    np.testing.assert_array_equal(gpu_ctx.read_sum().view(np.uint32), ref.view(np.uint32))
+
+
+def test_build_and_upload_small_inputs_spheres_and_rays(gpu_ctx):
+    """The smallest trees (1, 2, 3 primitives), spheres only, 17 spheres (no always list: reference-order pipelines only),
+    duplicates; closest hits through both walks against the oracle on the downloaded tree."""
+    from metalpathtracer_amd import capi
+    rng = np.random.default_rng(11)
+    for n, n_sph in ((1, 0), (1, 1), (2, 0), (3, 1), (9, 2), (40, 17), (300, 5)):
+        prims = np.zeros((n, 12), np.float32)
+        prims[:, 3] = 1.0
+        v0 = rng.uniform(-5, 5, (n, 3))
+        prims[:, 0:3], prims[:, 4:7], prims[:, 8:11] = v0, v0 + rng.uniform(-1, 1, (n, 3)), v0 + rng.uniform(-1, 1, (n, 3))
+        prims[:n_sph, 3], prims[:n_sph, 4:12] = 0.0, 0.0
+        prims[:n_sph, 4] = rng.uniform(0.3, 1.5, n_sph)
+        if n == 300:
+            prims[200:] = prims[100:200]                            # exact duplicates
+        mats = np.zeros((n, 8), np.float32)
+        mats[:, 0:3] = rng.choice([0.2, 0.5, 0.8], (n, 1))          # three distinct materials
+        gpu_ctx.build_and_upload(prims, mats)
+        bvh, idx = gpu_ctx.download_bvh()
+        _check_tree(bvh.reshape(-1, 8), idx, prims)
+        info = gpu_ctx.accel_info()
+        assert info["ordered_ok"] == (1 if n_sph <= 16 else 0)
+        m = 4096
+        o = (rng.normal(size=(m, 3)) * 8).astype(np.float32)
+        d = (rng.normal(size=(m, 3)) * 3 - o).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        t0, p0, n0, f0 = gpu_ctx.trace_rays(o, d)
+        buffers = (bvh, prims.reshape(-1, 3, 4), mats.reshape(-1, 2, 4), idx)
+        for i in range(0, m, 16):
+            to, po, no, fo = ob.first_hit(o[i], d[i], buffers)
+            assert po == p0[i] and (po < 0 or np.float32(to) == t0[i])
+        if n_sph <= 16:
+            t1, p1, n1, f1, fl = gpu_ctx.trace_rays_ordered(o, d)
+            np.testing.assert_array_equal(t0.view(np.uint32), t1.view(np.uint32))
+            np.testing.assert_array_equal(p0, p1)
+        assert (p0 >= 0).sum() > 0 or n < 3
+
+
+def test_build_and_upload_one_million_primitives_is_fast(gpu_ctx, tmp_path):
+    """SURVEY 8 f-1 at config-4 size: 1,000,003 primitives ready to render in tens of milliseconds of wall time (the reference's
+    builder: 8.2 s on one core; mpt_build_bvh + mpt_upload_scene: 0.55 s), and the render agrees with the reference-order one."""
+    import time
+    from metalpathtracer_amd import capi, host
+    from test_gpu_parity import _heightfield_obj
+    _heightfield_obj(str(tmp_path / "hf.obj"), 501, seed=1)
+    (tmp_path / "big.xml").write_text("""<Scene>
+  <Mesh file="hf.obj" position="0,-10,-30" scale="1.0" albedo="0.7,0.7,0.75" emission="0,0,0" materialType="0" emissionPower="0"/>
+  <Mesh file="hf.obj" position="0,35,-60" scale="0.6" albedo="1,1,1" emission="0,0,0" materialType="1.5" emissionPower="0"/>
+  <Sphere position="-15,18,-10" radius="9" albedo="0.95,0.95,0.95" emission="0,0,0" materialType="-1" emissionPower="0"/>
+  <Sphere position="15,18,-10" radius="9" albedo="1,1,1" emission="0,0,0" materialType="1.5" emissionPower="0"/>
+  <Sphere position="0,60,-20" radius="10" albedo="0,0,0" emission="1,0.9,0.7" materialType="0" emissionPower="5"/>
+</Scene>""")
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(str(tmp_path / "big.xml"), sc)
+    assert st == 0 and sc.getPrimitiveCount() == 1000003, log
+    prims, mats = sc.packed_primitives()
+    gpu_ctx.build_and_upload(prims, mats)                          # warm-up (allocator, code objects)
+    best = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter()
+        ms = gpu_ctx.build_and_upload(prims, mats)
+        best = min(best, time.perf_counter() - t0)
+    info = gpu_ctx.accel_info()
+    assert info["ordered_ok"] == 1 and info["always_spheres"] == 3 and info["nodes"] > 100000
+    assert best < 0.060, "1 M primitives took %.1f ms of wall time (device %.1f ms)" % (best * 1e3, ms)
+    W, H = 320, 180
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
+    img = {}
+    for pipe in (capi.PIPE_ORDERED, capi.PIPE_WAVELOCAL):
+        gpu_ctx.clear_sum()
+        gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_SCATTER, max_depth=16, sample_count=2, seed=(2, 7), pipeline=pipe)
+        img[pipe] = gpu_ctx.read_sum()
+    np.testing.assert_array_equal(img[capi.PIPE_ORDERED].view(np.uint32), img[capi.PIPE_WAVELOCAL].view(np.uint32))
