@@ -1517,6 +1517,12 @@ static int kat_sincos_impl(mpt_ctx* ctx, const float* u, uint64_t n, float* s, f
 }
 
 
+// MPT_GPU_BUILD=lbvh: the plain Karras tree; default: the PLOC clustering pass (mpt_lbvh.h)
+static bool gpu_build_uses_ploc() {
+    const char* e = getenv("MPT_GPU_BUILD");
+    return !(e && strcmp(e, "lbvh") == 0);
+}
+
 // ---- build -> render without the host (mpt_devbuild.h) -------------------------------------------------------------------------
 static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* mats, uint64_t n_prims, double* device_ms_out) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
@@ -1545,7 +1551,7 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     }
     hipEventRecord(e0, ctx->stream);
     mpt_devbuild::Built b;
-    hipError_t e = mpt_devbuild::build(ctx->stream, (float4*)d_p.p, (const float4*)d_m.p, n, leaf_max, n_spheres, b);
+    hipError_t e = mpt_devbuild::build(ctx->stream, (float4*)d_p.p, (const float4*)d_m.p, n, leaf_max, gpu_build_uses_ploc(), n_spheres, b);
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -1692,7 +1698,7 @@ extern "C" int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims,
         float ms = 0.0f;
         int leaf_max = 2;
         if (const char* lm = getenv("MPT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
-        hipError_t e = mpt_lbvh::build(ctx->stream, prims, (uint32_t)n_prims, leaf_max, bvh_out, n_nodes_out, prim_idx_out, &ms);
+        hipError_t e = mpt_lbvh::build(ctx->stream, prims, (uint32_t)n_prims, leaf_max, gpu_build_uses_ploc(), bvh_out, n_nodes_out, prim_idx_out, &ms);
         if (e != hipSuccess) return fail(ctx, MPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
         if (device_ms_out) *device_ms_out = ms;
         return MPT_OK;

@@ -186,6 +186,131 @@ __global__ void k_emit(int n, int leaf_max, const int2* child, const int2* range
     bvh_out[2 * (size_t)at + 1] = make_float4(hi.x, hi.y, hi.z, __int_as_float(cnt));
 }
 
+
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) ------------------------------------------------------
+// The quality pass of the GPU build.  The Karras tree above splits wherever the Morton codes first differ; PLOC instead
+// builds the tree bottom-up by merging, round after round, every pair of clusters that are each other's best partner —
+// the one with the smallest merged box among the MPT_PLOC_RADIUS neighbours on either side in Morton order.  The
+// result is a binary tree of agglomerative-clustering quality (measured: DESIGN.md 5) in ~30 rounds of three small
+// kernels.  Its subtrees are not contiguous in Morton order, so the primitives are re-ordered depth-first afterwards
+// and the node ids renumbered (root = internal node 0, leaf at depth-first position p = (n-1) + p): from there on the
+// tree looks exactly like a Karras tree to everything downstream (k_mark, k_emit, mpt_devbuild.h).
+#ifndef MPT_PLOC_RADIUS
+#define MPT_PLOC_RADIUS 16
+#endif
+struct PlocState {
+    uint32_t n_clusters;     // clusters alive in the current round
+    uint32_t next_internal;  // internal nodes created so far (creation order: 0, 1, ...)
+    uint32_t merges;         // of the current round
+};
+__device__ __forceinline__ float union_half_area(float4 al, float4 ah, float4 bl, float4 bh) {
+    const float dx = fmaxf(ah.x, bh.x) - fminf(al.x, bl.x), dy = fmaxf(ah.y, bh.y) - fminf(al.y, bl.y), dz = fmaxf(ah.z, bh.z) - fminf(al.z, bl.z);
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ void k_ploc_nn(const PlocState* st, const uint32_t* C, const float4* nlo, const float4* nhi, uint32_t* nn) {
+    const uint32_t N = st->n_clusters, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || N < 2u) return;
+    const float4 al = nlo[C[i]], ah = nhi[C[i]];
+    const uint32_t lo = i > MPT_PLOC_RADIUS ? i - MPT_PLOC_RADIUS : 0u, hi = i + MPT_PLOC_RADIUS < N - 1u ? i + MPT_PLOC_RADIUS : N - 1u;
+    float best = INFINITY;
+    uint32_t bj = i == lo ? i + 1u : lo;
+    for (uint32_t j = lo; j <= hi; ++j) {
+        if (j == i) continue;
+        float a = union_half_area(al, ah, nlo[C[j]], nhi[C[j]]);
+        if (!(a < 3.0e38f)) a = 3.0e38f;   // (a box with a NaN or an infinite side: still mergeable, last)
+        if (a < best) best = a, bj = j;   // ties: the smaller j, on both sides of a pair
+    }
+    nn[i] = bj;
+}
+__global__ void k_ploc_flags(const PlocState* st, const uint32_t* nn, uint32_t* merged, uint32_t* valid) {
+    const uint32_t N = st->n_clusters, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint32_t m = 0, v = 1;
+    if (N >= 2u) {
+        const uint32_t j = nn[i];
+        if (nn[j] == i) {   // mutual: the lower index carries the new node, the higher one disappears
+            m = i < j ? 1u : 0u;
+            v = i < j ? 1u : 0u;
+        }
+    }
+    merged[i] = m;
+    valid[i] = v;
+}
+__global__ void k_ploc_merge(PlocState* st, const uint32_t* C, const uint32_t* nn, const uint32_t* merged, const uint32_t* valid, const uint32_t* mslot,
+                             const uint32_t* vpos, int n, uint32_t* Cout, int2* child, int* parent, uint32_t* size, float4* nlo, float4* nhi) {
+    const uint32_t N = st->n_clusters, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (valid[i]) {
+        uint32_t id = C[i];
+        if (merged[i]) {
+            const uint32_t a = C[i], b = C[nn[i]];
+            id = st->next_internal + mslot[i];
+            child[id] = make_int2((int)a, (int)b);
+            parent[id] = -1;
+            parent[a] = (int)id;
+            parent[b] = (int)id;
+            size[id] = size[a] + size[b];
+            const float4 al = nlo[a], ah = nhi[a], bl = nlo[b], bh = nhi[b];
+            nlo[id] = make_float4(fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), 0.0f);
+            nhi[id] = make_float4(fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), 0.0f);
+        }
+        Cout[vpos[i]] = id;
+    }
+    (void)n;
+}
+__global__ void k_ploc_advance(PlocState* st, const uint32_t* merged, const uint32_t* mslot, const uint32_t* valid, const uint32_t* vpos) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t N = st->n_clusters;
+    if (N < 2u) return;
+    const uint32_t nm = mslot[N - 1] + merged[N - 1], nv = vpos[N - 1] + valid[N - 1];
+    st->next_internal += nm;
+    st->n_clusters = nv;
+    st->merges = nm;
+}
+__global__ void k_ploc_init(int n, const uint32_t* vals, const float4* blo, const float4* bhi, uint32_t* C, uint32_t* size, float4* nlo, float4* nhi, int* parent,
+                            PlocState* st) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) {
+        st->n_clusters = (uint32_t)n;
+        st->next_internal = 0u;
+        st->merges = 0u;
+    }
+    if (p >= n) return;
+    const uint32_t id = (uint32_t)(n - 1 + p);   // during the clustering: internal ids in creation order, leaf = (n-1) + Morton position
+    C[p] = id;
+    size[id] = 1u;
+    nlo[id] = blo[vals[p]];
+    nhi[id] = bhi[vals[p]];
+    parent[id] = -1;
+}
+// depth-first position of every node's first primitive: walking up, every time the node hangs on the right the left
+// sibling's primitives come first
+__global__ void k_ploc_first(int n, const int2* child, const int* parent, const uint32_t* size, uint32_t* first) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= 2 * n - 1) return;
+    uint32_t f = 0;
+    for (int y = node, p = parent[node]; p >= 0; y = p, p = parent[p])
+        if (y == child[p].y) f += size[child[p].x];
+    first[node] = f;
+}
+// renumber: internal id k (creation order, root last) -> (n-2) - k (root 0); leaf (n-1) + m -> (n-1) + first
+__device__ __forceinline__ int ploc_new_id(int n, int id, const uint32_t* first) { return id < n - 1 ? (n - 2) - id : (n - 1) + (int)first[id]; }
+__global__ void k_ploc_renumber(int n, const int2* child, const int* parent, const uint32_t* size, const uint32_t* first, const float4* nlo, const float4* nhi,
+                                const uint32_t* vals, int2* child2, int* parent2, int2* range2, float4* nlo2, float4* nhi2, uint32_t* vals2) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= 2 * n - 1) return;
+    const int id2 = ploc_new_id(n, node, first);
+    parent2[id2] = parent[node] < 0 ? -1 : ploc_new_id(n, parent[node], first);
+    nlo2[id2] = nlo[node];
+    nhi2[id2] = nhi[node];
+    if (node < n - 1) {
+        child2[id2] = make_int2(ploc_new_id(n, child[node].x, first), ploc_new_id(n, child[node].y, first));
+        range2[id2] = make_int2((int)first[node], (int)(first[node] + size[node] - 1u));
+    } else {
+        vals2[first[node]] = vals[node - (n - 1)];
+    }
+}
+
 struct Scratch {  // freed on every exit path
     std::vector<void*> ptrs;
     ~Scratch() {
@@ -227,10 +352,15 @@ struct Radix {
 
 // d_prims: device, 3 float4 per primitive.  Leaves everything of Radix on the device; synchronises the stream once to
 // read the output node count.
-static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, uint32_t n, int leaf_max, Radix& R) {
+static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, uint32_t n, int leaf_max, bool use_ploc, Radix& R) {
     int *arrived;
     unsigned long long *keys, *keys2;
-    uint32_t *vals0;
+    uint32_t *vals0, *vals_sorted;
+    struct Pinned {   // the few words read back per round go through pinned memory (a pageable target costs ~0.3 ms per copy)
+        uint32_t* p = nullptr;
+        ~Pinned() { if (p) hipHostFree(p); }
+    } pinned;
+    MPT_LB(hipHostMalloc((void**)&pinned.p, 64, hipHostMallocDefault));
     const size_t nn = 2 * (size_t)n - 1;
     R.n = n;
     R.leaf_max = leaf_max;
@@ -248,6 +378,7 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
     MPT_LB(sc.alloc(&keys2, n));
     MPT_LB(sc.alloc(&vals0, n));
     MPT_LB(sc.alloc(&R.vals, n));
+    MPT_LB(sc.alloc(&vals_sorted, n));
     MPT_LB(sc.alloc(&R.keep, nn + 1));
     MPT_LB(sc.alloc(&R.index, nn + 1));
     const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
@@ -257,18 +388,71 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
     hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, R.blo, R.bhi, R.cb);
     hipLaunchKernelGGL(k_morton, dim3(gn), dim3(B), 0, stream, (const float4*)R.blo, (const float4*)R.bhi, n, (const int*)R.cb, keys, vals0);
     size_t tmp_bytes = 0;
-    MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals0, R.vals, (int)n, 0, 63, stream));
+    MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals0, vals_sorted, (int)n, 0, 63, stream));
     char* tmp;
     MPT_LB(sc.alloc(&tmp, tmp_bytes));
-    MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals0, R.vals, (int)n, 0, 63, stream));
-    if (n > 1) {
-        hipLaunchKernelGGL(k_hierarchy, dim3(gn), dim3(B), 0, stream, (const unsigned long long*)keys2, (int)n, R.child, R.parent, R.range);
+    MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals0, vals_sorted, (int)n, 0, 63, stream));
+    if (n > 2 && use_ploc) {
+        // clustering on scratch arrays in creation order, then the renumbered tree into R's arrays
+        int2 *child0;
+        int *parent0;
+        float4 *nlo0, *nhi0;
+        uint32_t *C0, *C1, *size, *nn_, *merged, *valid, *mslot, *vpos, *first;
+        PlocState* st;
+        MPT_LB(sc.alloc(&child0, n));
+        MPT_LB(sc.alloc(&parent0, nn));
+        MPT_LB(sc.alloc(&nlo0, nn));
+        MPT_LB(sc.alloc(&nhi0, nn));
+        MPT_LB(sc.alloc(&C0, n));
+        MPT_LB(sc.alloc(&C1, n));
+        MPT_LB(sc.alloc(&size, nn));
+        MPT_LB(sc.alloc(&nn_, n));
+        MPT_LB(sc.alloc(&merged, n));
+        MPT_LB(sc.alloc(&valid, n));
+        MPT_LB(sc.alloc(&mslot, n));
+        MPT_LB(sc.alloc(&vpos, n));
+        MPT_LB(sc.alloc(&first, nn));
+        MPT_LB(sc.alloc(&st, 1));
+        size_t sb = 0;
+        MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, merged, mslot, (int)n, stream));
+        char* stmp;
+        MPT_LB(sc.alloc(&stmp, sb));
+        hipLaunchKernelGGL(k_ploc_init, dim3(gn), dim3(B), 0, stream, (int)n, (const uint32_t*)vals_sorted, (const float4*)R.blo, (const float4*)R.bhi, C0, size,
+                           nlo0, nhi0, parent0, st);
+        uint32_t alive = n;          // upper bound of the clusters alive (the exact count lives on the device)
+        for (int round = 0; round < 4096 && alive > 1u; ++round) {
+            const uint32_t g = (alive + B - 1) / B;
+            hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(B), 0, stream, (const PlocState*)st, (const uint32_t*)C0, (const float4*)nlo0, (const float4*)nhi0, nn_);
+            hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(B), 0, stream, (const PlocState*)st, (const uint32_t*)nn_, merged, valid);
+            MPT_LB(hipcub::DeviceScan::ExclusiveSum(stmp, sb, merged, mslot, (int)alive, stream));
+            MPT_LB(hipcub::DeviceScan::ExclusiveSum(stmp, sb, valid, vpos, (int)alive, stream));
+            hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(B), 0, stream, st, (const uint32_t*)C0, (const uint32_t*)nn_, (const uint32_t*)merged, (const uint32_t*)valid,
+                               (const uint32_t*)mslot, (const uint32_t*)vpos, (int)n, C1, child0, parent0, size, nlo0, nhi0);
+            hipLaunchKernelGGL(k_ploc_advance, dim3(1), dim3(64), 0, stream, st, (const uint32_t*)merged, (const uint32_t*)mslot, (const uint32_t*)valid, (const uint32_t*)vpos);
+            std::swap(C0, C1);
+            // every round merges at least one pair; in practice the count falls by ~40 %: read it back every few rounds
+            if ((round & 3) == 3 || alive <= 4096u) {
+                PlocState& h = *(PlocState*)pinned.p;
+                MPT_LB(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
+                MPT_LB(hipStreamSynchronize(stream));
+                alive = h.n_clusters;
+            }
+        }
+        if (alive != 1u) return hipErrorUnknown;
+        hipLaunchKernelGGL(k_ploc_first, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size, first);
+        hipLaunchKernelGGL(k_ploc_renumber, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size, (const uint32_t*)first,
+                           (const float4*)nlo0, (const float4*)nhi0, (const uint32_t*)vals_sorted, R.child, R.parent, R.range, R.nlo, R.nhi, R.vals);
     } else {
-        const int minus1 = -1;
-        MPT_LB(hipMemcpyAsync(R.parent, &minus1, 4, hipMemcpyHostToDevice, stream));
+        MPT_LB(hipMemcpyAsync(R.vals, vals_sorted, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+        if (n > 1) {
+            hipLaunchKernelGGL(k_hierarchy, dim3(gn), dim3(B), 0, stream, (const unsigned long long*)keys2, (int)n, R.child, R.parent, R.range);
+        } else {
+            const int minus1 = -1;
+            MPT_LB(hipMemcpyAsync(R.parent, &minus1, 4, hipMemcpyHostToDevice, stream));
+        }
+        hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, stream, (const uint32_t*)R.vals, (const float4*)R.blo, (const float4*)R.bhi, (int)n,
+                           (const int2*)R.child, (const int*)R.parent, R.nlo, R.nhi, arrived);
     }
-    hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, stream, (const uint32_t*)R.vals, (const float4*)R.blo, (const float4*)R.bhi, (int)n,
-                       (const int2*)R.child, (const int*)R.parent, R.nlo, R.nhi, arrived);
     hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int*)R.parent, (const int2*)R.range, R.keep);
     size_t scan_bytes = 0;
     MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
@@ -277,8 +461,9 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
     MPT_LB(hipMemsetAsync(R.keep + nn, 0, 4, stream));
     MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
     MPT_LB(hipGetLastError());
-    MPT_LB(hipMemcpyAsync(&R.n_out, R.index + nn, 4, hipMemcpyDeviceToHost, stream));
+    MPT_LB(hipMemcpyAsync(pinned.p, R.index + nn, 4, hipMemcpyDeviceToHost, stream));
     MPT_LB(hipStreamSynchronize(stream));
+    R.n_out = pinned.p[0];
     return hipSuccess;
 }
 
@@ -292,7 +477,7 @@ static hipError_t emit_reference_format(hipStream_t stream, const Radix& R, floa
 
 // prims: host, 12 floats per primitive (Scene::createTransformsBuffer).  bvh_out: host, room for 8 * (2n - 1) floats;
 // prim_idx_out: host, n ints.  Returns hipSuccess and the node count, or the failing HIP status.
-static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int leaf_max, float* bvh_out, uint64_t* n_nodes_out,
+static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int leaf_max, bool use_ploc, float* bvh_out, uint64_t* n_nodes_out,
                         int32_t* prim_idx_out, float* ms_out) {
     Scratch sc;
     float4 *d_prims, *d_bvh;
@@ -311,7 +496,7 @@ static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int 
     auto body = [&]() -> hipError_t {
         MPT_LB(hipEventRecord(e0, stream));
         Radix R;
-        MPT_LB(build_radix(stream, sc, d_prims, n, leaf_max, R));
+        MPT_LB(build_radix(stream, sc, d_prims, n, leaf_max, use_ploc, R));
         MPT_LB(emit_reference_format(stream, R, d_bvh, d_idx));
         MPT_LB(hipEventRecord(e1, stream));
         MPT_LB(hipStreamSynchronize(stream));
