@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "scene.xml"))
     ap.add_argument("--pipeline", default=os.environ.get("MPT_BENCH_PIPELINE", "default"),
                     choices=["default", "wavefront", "megakernel", "wavelocal", "ordered"])
-    ap.add_argument("--bvh", default="reference", choices=["reference", "binned", "gpu"],
-                    help="tree builder: the reference's sweep SAH (default: the drop-in behaviour), the host binned SAH, the GPU LBVH")
+    ap.add_argument("--bvh", default="reference", choices=["reference", "binned", "gpu", "device"],
+                    help="tree builder: the reference's sweep SAH (default: the drop-in behaviour), the host binned SAH, the GPU builder through "
+                         "the host (mpt_build_bvh + mpt_upload_scene), or build -> render on the device (mpt_build_and_upload)")
     ap.add_argument("--slots", type=int, default=0, help="wavefront width (ray slots per iteration), 0 = default")
     ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,16 +149,23 @@ def extra_workloads(ctx, capi, host, depth):
     """Untimed extras (N = 1), like serial_ms_per_render: ONE serial 1920x1080 x 256 spp render of north_star's "synthetic
     Cornell-style scene" and of bunny x20 (BASELINE.json configs[2]'s scene, on the tree the Renderer picks for it), so that
     the driver's record carries them.  HIP-event time of the whole render, best of two after a warm-up."""
+    import time
     out = []
-    for name, xml, bvh, cam in (("cornell.xml", "cornell.xml", host.BVH_REFERENCE_SWEEP, CORNELL_CAM),
-                                ("bunny20.xml", "bunny20.xml", host.BVH_BINNED_CENTROID, None)):
+    for name, xml, builder, cam in (("cornell.xml", "cornell.xml", "reference", CORNELL_CAM), ("bunny20.xml", "bunny20.xml", "device", None)):
         sc = host.Scene()
         st, log = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", xml), sc)
         if st != 0:
             out.append({"workload": name, "error": log[-200:]})
             continue
-        sc.buildBVH(bvh)
-        ctx.upload_scene(*sc.buffers())
+        t0 = time.perf_counter()
+        sc.buildBVH(host.BVH_REFERENCE_SWEEP)
+        if builder == "device":                      # what the Renderer does for a scene of this size: build -> render on the device
+            prims, mats = sc.packed_primitives()
+            t0 = time.perf_counter()
+            ctx.build_and_upload(prims, mats)
+        else:
+            ctx.upload_scene(*sc.buffers())
+        setup_ms = (time.perf_counter() - t0) * 1e3
         W, H, spp = 1920, 1080, 256
         ctx.resize(W, H)
         ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam))
@@ -170,7 +178,7 @@ def extra_workloads(ctx, capi, host, depth):
             if k and (best is None or s["total_ms"] < best["total_ms"]):
                 best = s
         out.append({"workload": "%s %dx%d x %d spp, depth %d, one serial render" % (name, W, H, spp, depth),
-                    "prims": sc.getPrimitiveCount(), "bvh_builder": {0: "reference", 1: "binned", 2: "gpu"}[bvh],
+                    "prims": sc.getPrimitiveCount(), "bvh_builder": builder, "build_and_upload_ms": setup_ms,
                     "pipeline": PIPE_NAMES[ctx.accel_info()["auto_pipeline"]], "ms_per_render": best["total_ms"],
                     "mrays_per_s": best["rays"] / best["total_ms"] / 1e3, "rays": best["rays"], "paths": best["paths"]})
     return out
@@ -210,11 +218,18 @@ def main():
     st, log = host.SceneLoader.LoadSceneFromXML(args.scene, sc)
     if st != 0:
         sys.exit("cannot load %s: %s" % (args.scene, log))
-    sc.buildBVH({"reference": host.BVH_REFERENCE_SWEEP, "binned": host.BVH_BINNED_CENTROID, "gpu": host.BVH_GPU_LBVH}[args.bvh])
-    buffers = sc.buffers()
-    P, T = sc.getPrimitiveCount(), sc.getTriangleCount()
     ctx = capi.Context(local)
-    ctx.upload_scene(*buffers)
+    if args.bvh == "device":
+        sc.buildBVH(host.BVH_REFERENCE_SWEEP)        # (sorts the primitives as every builder does; this tree is not used)
+        prims, mats = sc.packed_primitives()
+        ctx.build_and_upload(prims, mats)
+        bvh, idx = ctx.download_bvh()                # the tree in the reference's format: what the CPU leg walks
+        buffers = (bvh, prims, mats, idx)
+    else:
+        sc.buildBVH({"reference": host.BVH_REFERENCE_SWEEP, "binned": host.BVH_BINNED_CENTROID, "gpu": host.BVH_GPU_LBVH}[args.bvh])
+        buffers = sc.buffers()
+        ctx.upload_scene(*buffers)
+    P, T = sc.getPrimitiveCount(), sc.getTriangleCount()
     W, H = args.width, args.height
     ctx.resize(W, H)
     ctx.set_uniforms(host.make_uniforms(W, H, P, T))
@@ -299,7 +314,7 @@ def main():
             "config": {
                 "workload": "scene.xml %dx%d x %d spp per step, depth %d (%d steps timed)" % (W, H, spp, args.depth,
                                                                                            args.steps),
-                "prims": P, "bvh_nodes": sc.getBVHNodeCount(), "bvh_builder": args.bvh, "rng": "philox4x32-10 (pixel,sample,bounce)",
+                "prims": P, "bvh_nodes": len(buffers[0]), "bvh_builder": args.bvh, "rng": "philox4x32-10 (pixel,sample,bounce)",
                 "pipeline": PIPE_NAMES[pipe],
                 "parallelism": "8x8-tile interleave over %d rank(s)%s" % (world, " + 1 RCCL reduce(sum) of the HDR framebuffer" if world > 1 else ""),
                 "paths": paths_total, "rays": rays_total, "rays_per_path": rays_total / max(1, paths_total),
@@ -319,7 +334,7 @@ def main():
             rays_per_launch = rays_local / launches
             sec_per_launch = kernel_ms * 1e-3 / launches
             workload = {"scene": os.path.basename(args.scene), "width": W, "height": H, "spp": spp, "depth": args.depth,
-                        "bvh": {"reference": 0, "binned": 1, "gpu": 2}[args.bvh], "env": capi.knob_env()}
+                        "bvh": {"reference": 0, "binned": 1, "gpu": 2, "device": 3}[args.bvh], "env": capi.knob_env()}
             prof, why = counter_profile(PIPE_KERNEL[pipe], workload)
             rf = {"kernel": PIPE_KERNEL[pipe], "launches": launches, "avg_launch_ms": kernel_ms / launches,
                   "rays_per_launch": rays_per_launch}

@@ -134,6 +134,23 @@ struct SceneDev {
 __device__ __forceinline__ int prim_type(float4 p0) { return __float_as_int(p0.w) & 1; }
 __device__ __forceinline__ uint32_t prim_ref_leaf(float4 p0) { return (uint32_t)__float_as_int(p0.w) >> 1; }
 
+// Diagnostics build (-DMPT_CLOCK_STAMP): the shader clock a kernel actually holds = delta s_memtime / delta s_memrealtime x 100 MHz
+// (MI355X_MICROARCH.md, DVFS item 6), summed over all waves of the trace kernels.  Nothing else reads these words.
+#ifdef MPT_CLOCK_STAMP
+__device__ unsigned long long g_clock[2];
+#define MPT_CLOCK_BEGIN() const unsigned long long clk_t0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
+#define MPT_CLOCK_END()                                                                    \
+    do {                                                                                   \
+        if ((threadIdx.x & 63u) == 0) {                                                    \
+            atomicAdd(&g_clock[0], __builtin_amdgcn_s_memtime() - clk_t0_);                \
+            atomicAdd(&g_clock[1], __builtin_amdgcn_s_memrealtime() - clk_r0_);            \
+        }                                                                                  \
+    } while (0)
+#else
+#define MPT_CLOCK_BEGIN() do { } while (0)
+#define MPT_CLOCK_END() do { } while (0)
+#endif
+
 // true in exactly one lane of the currently active lanes (used to count wave-level loop trips)
 __device__ __forceinline__ bool first_active_lane() {
     const uint32_t me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -313,29 +330,36 @@ __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes 
             round_trips++;
 #endif
             const uint32_t j = i < n_nodes - 1u ? i : n_nodes - 1u;
-            float4 n0, n1;
-            if (ALL_LDS || j < n_lds) {
-                const v4f a = lds_nodes[2 * j], b = lds_nodes[2 * j + 1];
-                n0 = make_float4(a.x, a.y, a.z, a.w);
-                n1 = make_float4(b.x, b.y, b.z, b.w);
-            } else {
-                n0 = sc.nodes[2 * j];
-                n1 = sc.nodes[2 * j + 1];
+            float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
+            bool box = false;
+            // Lanes that are not searching sit the trip out under the exec mask (one s_and_saveexec / s_or per trip): they issue
+            // no LDS read and toggle no ALU, while the loop stays wave-uniform in its control flow.  Letting them compute on a
+            // clamped node and discard (no branch at all) issues the same instructions but burns power on 16-60 % idle lanes of
+            // a kernel whose clock is power-limited: 22.5 -> 21.95 ms per 256-spp render of scene.xml with the mask.
+            if (searching) {
+                if (ALL_LDS || j < n_lds) {
+                    const v4f a = lds_nodes[2 * j], b = lds_nodes[2 * j + 1];
+                    n0 = make_float4(a.x, a.y, a.z, a.w);
+                    n1 = make_float4(b.x, b.y, b.z, b.w);
+                } else {
+                    n0 = sc.nodes[2 * j];
+                    n1 = sc.nodes[2 * j + 1];
+                }
+                // PathTracing.h:52-72 slab test with tMin = 1e-4, tMax = best t.  The per-axis early-outs
+                // are equivalent to one test after the third axis (tMin only grows, tMax only shrinks).
+                float t0 = (n0.x - o.x) * idx, t1 = (n1.x - o.x) * idx;
+                float lo = fmaxf(0.0001f, idx < 0.0f ? t1 : t0);
+                float hi = fminf(best_t, idx < 0.0f ? t0 : t1);
+                t0 = (n0.y - o.y) * idy;
+                t1 = (n1.y - o.y) * idy;
+                lo = fmaxf(lo, idy < 0.0f ? t1 : t0);
+                hi = fminf(hi, idy < 0.0f ? t0 : t1);
+                t0 = (n0.z - o.z) * idz;
+                t1 = (n1.z - o.z) * idz;
+                lo = fmaxf(lo, idz < 0.0f ? t1 : t0);
+                hi = fminf(hi, idz < 0.0f ? t0 : t1);
+                box = hi > lo;
             }
-            // PathTracing.h:52-72 slab test with tMin = 1e-4, tMax = best t.  The per-axis early-outs
-            // are equivalent to one test after the third axis (tMin only grows, tMax only shrinks).
-            float t0 = (n0.x - o.x) * idx, t1 = (n1.x - o.x) * idx;
-            float lo = fmaxf(0.0001f, idx < 0.0f ? t1 : t0);
-            float hi = fminf(best_t, idx < 0.0f ? t0 : t1);
-            t0 = (n0.y - o.y) * idy;
-            t1 = (n1.y - o.y) * idy;
-            lo = fmaxf(lo, idy < 0.0f ? t1 : t0);
-            hi = fminf(hi, idy < 0.0f ? t0 : t1);
-            t0 = (n0.z - o.z) * idz;
-            t1 = (n1.z - o.z) * idz;
-            lo = fmaxf(lo, idz < 0.0f ? t1 : t0);
-            hi = fminf(hi, idz < 0.0f ? t0 : t1);
-            const bool box = hi > lo;
             const uint32_t A = __float_as_uint(n0.w), B = __float_as_uint(n1.w);  // links: box hit / box missed
             if (COUNT) {
                 wc.node_visits += searching ? 1u : 0u;

@@ -1925,6 +1925,17 @@ extern "C" int mpt_debug_ot_times(unsigned long long* out32, int reset) {   // [
 }
 #endif
 
+#ifdef MPT_CLOCK_STAMP
+extern "C" int mpt_debug_clock(unsigned long long* out2, int reset) {   // sums over waves: shader cycles, 100 MHz ticks
+    hipError_t e = hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_clock), 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[2] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_clock), z, 16);
+    }
+    return (int)e;
+}
+#endif
+
 #ifdef MPT_DEBUG_WAVE_TIMES
 static mpt_ctx* g_dbg_ctx = nullptr;
 extern "C" void mpt_debug_bind(mpt_ctx* ctx) { g_dbg_ctx = ctx; }

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                                                                  uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_nodes_raw[];
     stage_nodes(pp.scene, lds_nodes_raw);
+    MPT_CLOCK_BEGIN();
     const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_paths = pp.desc->total_paths;
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         reg[6] = wc.t_leaf;
     }
 #endif
+    MPT_CLOCK_END();
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
 }
 

@@ -519,6 +519,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                                                                           uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_raw[];
     ot_stage(pp.scene, ac, lds_raw);
+    MPT_CLOCK_BEGIN();
     const LdsNodes lds = (LdsNodes)lds_raw;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_paths = pp.desc->total_paths;
@@ -826,6 +827,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         }
     }
 #endif
+    MPT_CLOCK_END();
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
     {
         unsigned long long a = n_flagged, b = n_parked;

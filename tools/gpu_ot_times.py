@@ -35,3 +35,15 @@ if w[2]:
 if w[2]:
     print("  walk: node loop %.1f %% of the walk cycles, %.0f cycles per wave trip (%d trips); leaf loop %.0f cycles per wave trip (%d trips); %d rounds"
           % (100.0 * w[0] / max(1, w[0] + w[1]), w[0] / w[2], w[2], w[1] / max(1, w[3]), w[3], w[4]))
+
+out = os.environ.get("JSON_OUT")
+if out:
+    import json
+    J = {"what": "k_ordered on %s 1920x1080, %d spp, depth 8: diagnostics build (-DMPT_OT_TIMES), s_memtime around the regions of every step summed over all "
+                 "waves (the lane counters of this build perturb the timing: the percentages and the lane utilisation are what it is for)" % (name, spp),
+         "build": capi.build_id(), "kernel_ms_instrumented": s["total_ms"], "rays": s["rays"], "exact_retraces": s["exact_retraces"], "tree_parked": s["tree_parked"],
+         "cycles_by_region_pct": {n: 100.0 * c / tot for n, c in zip(names, v[:8])},
+         "steps": {kinds[k]: {"steps": v[8 + k], "lanes_per_step": v[16 + k] / v[8 + k]} for k in range(5) if v[8 + k]},
+         "walk": {"node_loop_lane_utilisation_pct": 100.0 * w[5] / (64.0 * max(1, w[2])), "leaf_loop_lane_utilisation_pct": 100.0 * w[6] / (64.0 * max(1, w[3])),
+                  "node_trips": w[2], "leaf_trips": w[3], "rounds": w[4], "node_loop_share_of_walk_pct": 100.0 * w[0] / max(1, w[0] + w[1])}}
+    json.dump(J, open(out, "w"), indent=1)

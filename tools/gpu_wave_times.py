@@ -45,8 +45,17 @@ for name, sel in (("latest 2%", late), ("earliest 50%", early)):
     print(name, "steps after last claim [prim,L0..L4] mean", st_.mean(0).round(1), "left at exhaust [L0..L4] mean", lf.mean(0).round(1),
           "last blk mean %.0f" % buf[sel, 6].astype(np.float64).mean(), "exh-claim mean %.0f us" % (exh[sel] - claim[sel]).mean(), "drain mean %.0f" % (end[sel] - exh[sel]).mean())
 
+import json
+J = {"what": "k_wavelocal on scene.xml 1920x1080, %s spp, depth 8: diagnostics build (-DMPT_DEBUG_WAVE_TIMES), s_memtime around the regions of every step "
+             "summed over all waves; per-step-kind counters with MPT_FLAG_COUNT_WORK (tools/gpu_wave_times.py)" % os.environ.get("SPP", "64"),
+     "build": capi.build_id(), "kernel_ms": st["trace_kernel_ms"], "drain_per_wave_us_p50": float(np.percentile(end - exh, 50)),
+     "drain_per_wave_us_p99": float(np.percentile(end - exh, 99)), "last_claim_us_p50": float(np.percentile(claim, 50)),
+     "wave_end_us_max": float(end.max())}
 tot = reg[:, :5].sum()
 names = ["step choice + claim", "ray fetch (primary generation / ring pop)", "closest hit", "shading", "ring push"]
+J["cycles_by_region_pct"] = {nm: 100 * reg[:, i].sum() / tot for i, nm in enumerate(names)}
+J["cycles_by_region_pct"]["closest hit: box-test loop"] = 100 * reg[:, 5].sum() / tot
+J["cycles_by_region_pct"]["closest hit: primitive loop"] = 100 * reg[:, 6].sum() / tot
 print("shader-clock cycles by region (sum over waves, %% of the total of %.3g):" % tot)
 for i, nm in enumerate(names): print("  %-44s %5.1f %%" % (nm, 100 * reg[:, i].sum() / tot))
 print("  inside closest hit: box-test loop %.1f %%, leaf (primitive) loop %.1f %% of the total" % (100 * reg[:, 5].sum() / tot, 100 * reg[:, 6].sum() / tot))
@@ -59,6 +68,14 @@ if flags:
         st_, bt, bw, pt, pw, rays, dn = lv[i, :7]
         wl = lv[i, 7]
         if st_ == 0: continue
+        J.setdefault("per_step_kind", {})[nm] = {"steps": st_, "rays_per_step": rays / st_, "done_pct": 100 * dn / max(1, rays), "box_trips_per_step": bt / st_,
+                                                "box_lane_utilisation_pct": 100 * bw / max(1, 64 * bt), "prim_trips_per_step": pt / st_,
+                                                "prim_lane_utilisation_pct": 100 * pw / max(1, 64 * pt), "cost_share_pct": 100 * (bt * 26 + pt * 70) / tot,
+                                                "box_slots_waiting_with_a_leaf_pct": 100 * wl / max(1, 64 * bt)}
         print("  %-8s steps %9d  rays/step %5.1f  done %5.1f %%  box trips %7.1f util %4.1f %%  prim trips %6.1f util %4.1f %%  cost share %4.1f %%  box slots waiting with a leaf %4.1f %%" % (
             nm, st_, rays / st_, 100 * dn / max(1, rays), bt / st_, 100 * bw / max(1, 64 * bt), pt / st_, 100 * pw / max(1, 64 * pt),
             100 * (bt * 26 + pt * 70) / tot, 100 * wl / max(1, 64 * bt)))
+
+out = os.environ.get("JSON_OUT")
+if out:
+    json.dump(J, open(out, "w"), indent=1)
