@@ -453,24 +453,35 @@ struct PathRngDev {
     uint32_t lit_seed;       // literal: the stuck seed entering rayColor
 };
 
-// PathTracing.h:25-31 (literal: same u for z and phi, seed never advances).
-__device__ __forceinline__ F3 random_unit_vector(const ShadeParams& sp, const PathRngDev& g, uint32_t bounce,
-                                                 float& u_extra) {
-    float z, s, c;
+// PathTracing.h:25-31 (literal: same u for z and phi, seed never advances), in two halves: the random
+// numbers of the bounce depend on (pixel, sample, bounce) only, so shade_bounce draws them BEFORE it fetches the hit's
+// primitive and material records — the 60-instruction Philox chain then runs under the latency of those loads instead of
+// behind it.
+struct BounceRandoms {
+    float uz, uphi, u_extra;   // z = 2 uz - 1, phi = 2 pi uphi, Fresnel test
+};
+__device__ __forceinline__ BounceRandoms draw_bounce_randoms(const ShadeParams& sp, const PathRngDev& g, uint32_t bounce) {
+    BounceRandoms b;
     if (sp.rng_mode == 0) {
-        float u = pcg_float(g.lit_seed);
-        z = 2.0f * u - 1.0f;
-        float t = 2.0f * 3.14159274101257324f * u;
+        b.uz = b.uphi = b.u_extra = pcg_float(g.lit_seed);
+    } else {
+        const U4 r = philox4x32_10<true>(g.pixel, g.sample, bounce, 0u, sp.seed_lo, sp.seed_hi);
+        b.uz = u01(r.x);
+        b.uphi = u01(r.y);
+        b.u_extra = u01(r.z);
+    }
+    return b;
+}
+__device__ __forceinline__ F3 random_unit_vector(const ShadeParams& sp, const BounceRandoms& b) {
+    float z = 2.0f * b.uz - 1.0f, s, c;
+    if (sp.rng_mode == 0) {
+        const float t = 2.0f * 3.14159274101257324f * b.uphi;
         s = sinf(t);
         c = cosf(t);
-        u_extra = u;
     } else {
-        U4 r = philox4x32_10<true>(g.pixel, g.sample, bounce, 0u, sp.seed_lo, sp.seed_hi);
-        z = 2.0f * u01(r.x) - 1.0f;
-        sincos_2pi(u01(r.y), s, c);
-        u_extra = u01(r.z);
+        sincos_2pi(b.uphi, s, c);
     }
-    float rr = sqrtf(1.0f - z * z);
+    const float rr = sqrtf(1.0f - z * z);
     return f3(rr * c, rr * s, z);
 }
 
@@ -508,6 +519,7 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, LdsNodes lds, c
         ps.La += 1.0f;
         return false;
     }
+    const BounceRandoms rnd = draw_bounce_randoms(sp, g, ps.bounce);
     HitInfo h = finish_hit(sc, lds, ps.o, ps.d, t, prim);
     if ((uint32_t)h.orig_id >= sp.primitive_count) return false;  // PathTracing.h:234-236
     float4 m0, m1;
@@ -527,8 +539,8 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, LdsNodes lds, c
         ps.L.z += ps.thr.z * m1.z * power;
         ps.La += power;
     }
-    float u_extra;
-    F3 ruv = random_unit_vector(sp, g, ps.bounce, u_extra);
+    const float u_extra = rnd.u_extra;
+    F3 ruv = random_unit_vector(sp, rnd);
     F3 nd;
     bool through = false;
     if (sp.bsdf_mode == 0 || mtype == 0.0f) {

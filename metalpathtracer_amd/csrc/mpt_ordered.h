@@ -13,9 +13,16 @@
 //   * the winner fails that final check (6.5e-4 of the rays on scene.xml: hits on the r = 10^4 ground sphere whose t
 //     is wrong by up to 1e-3 — catastrophic cancellation — and lands in front of its own leaf box).
 // Sub-trees are culled only when they start beyond best t * (1 + 2^-10) + eps_abs; own leaf boxes contain the
-// reference leaf boxes (padded), so every primitive the reference could accept in front of the winner is seen here.
-// tests/experiments/ordered_proto.cpp replays this rule on the CPU against the oracle: 0 differences in 890 M rays of
-// the headline render (9 of the flagged rays would have differed); the GPU tests compare whole renders bit for bit.
+// reference leaf boxes (padded), so every primitive the reference could accept in front of the winner is seen here —
+// EXCEPT a triangle whose computed t is an artefact: in front of the triangle's own box by more than that margin, which
+// needs a ray within ~1e-5 / |e1 x e2| of the triangle's plane (|det| just above the reference's 1e-5 threshold, t = f *
+// dot(e2, q) without significant digits).  Its box is culled by distance here; the reference computes the bogus t if it
+// visits that leaf before the true hit.  The margin is EMPIRICAL, not a bound: a rule that covers those rays needs boxes
+// inflated by ~0.06 |e1||e2| |o - v0| (a leaf size on bunny x20).  tests/experiments/ordered_proto.cpp replays
+// the rule on the CPU against the oracle: 0 differences in 890 M rays of the headline render (9 of the flagged rays would
+// have differed); the GPU tests compare whole renders bit for bit (0 differences in 1.3e11 rays of rendering) and aim
+// 1e8 rays along the planes of slivers, needles and huge triangles (tests/test_gpu_adversarial.py: 6e-6 of THOSE differ,
+// every one verified in exact arithmetic to be such an artefact of the reference).  include/mpt.h states this at the ABI.
 //
 // Pipeline shape (per persistent wave; rings as in k_wavelocal, but sorted by KIND of work instead of by trip budget, so
 // that every expensive piece of code runs at full width):

@@ -211,3 +211,31 @@ def test_build_and_upload_one_million_primitives_is_fast(gpu_ctx, tmp_path):
         gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_SCATTER, max_depth=16, sample_count=2, seed=(2, 7), pipeline=pipe)
         img[pipe] = gpu_ctx.read_sum()
     np.testing.assert_array_equal(img[capi.PIPE_ORDERED].view(np.uint32), img[capi.PIPE_WAVELOCAL].view(np.uint32))
+
+
+def test_cli_renders_bunny20_on_the_device_built_tree(gpu_ctx, tmp_path):
+    """mpt_render (Renderer facade): a batch render of a scene of >= 8192 primitives builds its tree on the device (--bvh auto,
+    the default) and gives the image mpt_build_and_upload + mpt_render give through the C ABI."""
+    import json, os, subprocess
+    from conftest import ROOT
+    from metalpathtracer_amd import capi, host
+    exe = os.path.join(ROOT, "metalpathtracer_amd", "lib", "mpt_render")
+    out = str(tmp_path / "o.pfm")
+    r = subprocess.run([exe, "--scene", scene_path("bunny20.xml"), "--width", "96", "--height", "54", "--spp", "2", "--depth", "8", "--seed", "5",
+                        "--out", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "build -> render without the host" in r.stdout and "BVH built on the device" in r.stdout
+    raw = open(out, "rb").read()
+    hdr = b"PF\n96 54\n-1.0\n"
+    img = np.frombuffer(raw[len(hdr):], np.float32).reshape(54, 96, 3)[::-1]
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(scene_path("bunny20.xml"), sc)
+    assert st == 0, log
+    sc.buildBVH()
+    prims, mats = sc.packed_primitives()
+    gpu_ctx.build_and_upload(prims, mats)
+    gpu_ctx.resize(96, 54)
+    gpu_ctx.set_uniforms(host.make_uniforms(96, 54, sc.getPrimitiveCount(), sc.getTriangleCount()))
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=2, seed=(5, 0))
+    np.testing.assert_array_equal(img, gpu_ctx.read_sum()[..., :3] * np.float32(0.5))
