@@ -38,9 +38,19 @@ def load(xml, mode):
     return sc, time.perf_counter() - t0
 
 
-def measure(name, sc, W, H, spp, depth, bsdf, cam, shard_count, reps=2):
+DEVICE = "device"   # not a Scene::BuildMode: mpt_build_and_upload (build -> render on the device)
+
+
+def measure(name, sc, W, H, spp, depth, bsdf, cam, shard_count, reps=2, device_build=False):
     ctx = capi.Context(0)
-    ctx.upload_scene(*sc.buffers())
+    if device_build:
+        prims, mats = sc.packed_primitives()
+        ctx.build_and_upload(prims, mats)
+        t0 = time.perf_counter()
+        ctx.build_and_upload(prims, mats)
+        print("    (mpt_build_and_upload: %.1f ms wall, own tree of %d nodes)" % ((time.perf_counter() - t0) * 1e3, ctx.accel_info()["nodes"]))
+    else:
+        ctx.upload_scene(*sc.buffers())
     ctx.resize(W, H)
     ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam))
     best = None
@@ -66,12 +76,15 @@ def main():
     sc, _ = load(os.path.join(ASSETS, "scene.xml"), host.BVH_REFERENCE_SWEEP)
     measure("cfg1 scene.xml 1920x1080x256 d8", sc, 1920, 1080, 256 // d, 8, capi.BSDF_LAMBERT, None, 1)
     measure("     scene.xml 1920x1080x256 d32", sc, 1920, 1080, 256 // d, 32, capi.BSDF_LAMBERT, None, 1)
-    trees = ((host.BVH_REFERENCE_SWEEP, "reference tree"), (host.BVH_BINNED_CENTROID, "binned-SAH tree"), (host.BVH_GPU_LBVH, "GPU LBVH"))
+    trees = ((host.BVH_REFERENCE_SWEEP, "reference tree"), (host.BVH_BINNED_CENTROID, "binned-SAH tree"), (host.BVH_GPU_LBVH, "GPU tree through the host"),
+             (DEVICE, "device build"))
     for mode, tag in trees:
-        sc, tb = load(os.path.join(ASSETS, "bunny20.xml"), mode)
-        print("bunny20 %s: %d prims, %d nodes, build %.3f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
-        measure("cfg2 bunny20 1920x1080x1024 d8, %s" % tag, sc, 1920, 1080, 1024 // d, 8, capi.BSDF_LAMBERT, None, 1, reps=1)
-        measure("cfg3 bunny20 3840x2160x1024 d8, 1/8 tile shard, %s" % tag, sc, 3840, 2160, 1024 // d, 8, capi.BSDF_LAMBERT, None, 8, reps=1)
+        dev = mode == DEVICE
+        sc, tb = load(os.path.join(ASSETS, "bunny20.xml"), host.BVH_REFERENCE_SWEEP if dev else mode)
+        if not dev:
+            print("bunny20 %s: %d prims, %d nodes, build %.3f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
+        measure("cfg2 bunny20 1920x1080x1024 d8, %s" % tag, sc, 1920, 1080, 1024 // d, 8, capi.BSDF_LAMBERT, None, 1, reps=1, device_build=dev)
+        measure("cfg3 bunny20 3840x2160x1024 d8, 1/8 tile shard, %s" % tag, sc, 3840, 2160, 1024 // d, 8, capi.BSDF_LAMBERT, None, 8, reps=1, device_build=dev)
     tmp = tempfile.mkdtemp()
     heightfield(os.path.join(tmp, "hf.obj"), 501, 1)
     xml = os.path.join(tmp, "big.xml")
@@ -83,10 +96,12 @@ def main():
   <Sphere position="0,60,-20" radius="10" albedo="0,0,0" emission="1,0.9,0.7" materialType="0" emissionPower="5"/>
 </Scene>""" % (tmp, tmp))
     for mode, tag in trees:
-        sc, tb = load(xml, mode)
-        print("1M-tri heightfields %s: %d prims, %d nodes, build %.3f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
+        dev = mode == DEVICE
+        sc, tb = load(xml, host.BVH_BINNED_CENTROID if dev else mode)
+        if not dev:
+            print("1M-tri heightfields %s: %d prims, %d nodes, build %.3f s" % (tag, sc.getPrimitiveCount(), sc.getBVHNodeCount(), tb))
         measure("cfg4 1M tris glass+mirror 1920x1080x4096 d16, 1/8 tile shard, %s" % tag, sc, 1920, 1080, 4096 // d, 16,
-                capi.BSDF_SCATTER, None, 8, reps=1)
+                capi.BSDF_SCATTER, None, 8, reps=1, device_build=dev)
 
 
 main()
