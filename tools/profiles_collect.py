@@ -22,4 +22,21 @@ for f in ("bench_kernel_stats.csv", "devbuild_kernel_stats.csv", "bench_under_ro
         shutil.copy(src, os.path.join(P, "%s_%s" % (tag, f)))
     else:
         print("missing", src)
+# the dominant kernel's launches of the profiled bench run, in order, with what each one was: the summary CSV averages the
+# scene.xml steps together with the untimed extra workloads (Cornell, bunny x20), this separates them
+import csv
+trace = os.path.join(G, "bench_trace", "b_kernel_trace.csv")
+if os.path.exists(trace):
+    rows = [r for r in csv.DictReader(open(trace)) if "k_wavelocal" in r["Kernel_Name"] or "k_ordered" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    line = [l for l in open(os.path.join(G, tag + "_bench_under_rocprof.json")) if l.startswith("{")][-1]
+    b = json.loads(line)
+    K, Wm = b["steps"], b["warmup"]
+    labels = ["lane set-up"] * 2 + ["warm-up"] * Wm + ["timed step"] * K + ["serial render"] * min(3, K) + ["extra: cornell.xml"] * 3 + ["extra: bunny20.xml"] * 3
+    launches = [{"kernel": r["Kernel_Name"].split("(")[0].replace("void ", ""), "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6,
+                 "what": labels[i] if i < len(labels) else "?"} for i, r in enumerate(rows)]
+    timed = [x["ms"] for x in launches if x["what"] == "timed step"]
+    json.dump({"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d" % (K, Wm),
+               "timed_steps_avg_ms": sum(timed) / max(1, len(timed)), "bench_line_avg_launch_ms": b["roofline"]["avg_launch_ms"],
+               "launches": launches}, open(os.path.join(P, tag + "_bench_launches.json"), "w"), indent=1)
 print(sorted(f for f in os.listdir(P) if f.startswith(tag)))
