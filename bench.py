@@ -358,8 +358,7 @@ def main():
                               "measured_clock_note": "GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the PROFILED launch (profiled passes "
                                                      "clock lower than un-profiled ones)",
                               "instr_per_ray": prof["valu_per_ray"], "lane_utilisation": prof["lane_utilisation"],
-                              "lane_utilisation_note": "exec-mask utilisation (SQ_THREAD_CYCLES_VALU / 64 SQ_INSTS_VALU): the "
-                                                       "box-test loop is wave-uniform, lanes that ride along count as active",
+                              "lane_utilisation_note": "exec-mask utilisation (SQ_THREAD_CYCLES_VALU / 64 SQ_INSTS_VALU)",
                               "salu_per_valu": prof["salu_per_ray"] / prof["valu_per_ray"]}
                 # the scalar unit: one per CU, one instruction per cycle, shared by the CU's four SIMDs
                 salu_rate = prof["salu_per_ray"] * rays_per_launch / sec_per_launch / 1e9
