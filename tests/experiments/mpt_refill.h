@@ -571,3 +571,124 @@ __device__ __forceinline__ bool ot_walk_u(const AccelDev& ac, const SceneDev& sc
                 }
             }
 #endif
+
+// ---- top-up of the last tree-walk ring's step (MPT_OT_CARRY, round 3): unfinished walks stay in their lanes and the next
+// step fills the free lanes from the ring instead of parking 24 rays.  Measured slower: scene.xml 21.1 -> 24.4 ms, bunny x20
+// 64.4 -> 72.0 ms (binned tree, 256 spp; bit-identical output): the 13 carried registers spill across shade_bounce
+// (25 VGPRs to scratch) and the hits are shaded at <= 40 of 64 lanes however the step ends.  The patch against mpt_ordered.h:
+#if 0
+diff --git a/metalpathtracer_amd/csrc/mpt_ordered.h b/metalpathtracer_amd/csrc/mpt_ordered.h
+index 13455a6..b123c09 100644
+--- a/metalpathtracer_amd/csrc/mpt_ordered.h
++++ b/metalpathtracer_amd/csrc/mpt_ordered.h
+@@ -548,11 +548,25 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
+     WorkCount wc = {};
+ #ifdef MPT_OT_TIMES
+     unsigned long long ot_acc[OT_NREG] = {}, ot_steps[MPT_OT_RINGS + 1] = {}, ot_lanes[MPT_OT_RINGS + 1] = {};
++#endif
++#ifdef MPT_OT_CARRY
++    // unfinished walks of a step of the last tree-walk ring stay in their lanes (registers + LDS stack column) and the next
++    // step tops the wave up from the ring, instead of parking them (144 bytes written and read back per ray)
++    bool carry = false;
++    uint32_t n_carry = 0u;  // wave-uniform
++    F3 c_o = f3(0, 0, 0), c_d = f3(0, 0, 0);
++    float c_tx = 0.f, c_ty = 0.f, c_T = 0.f;
++    int c_W = -1;
++    uint32_t c_cur = 0u, c_sp = 0u, c_at = 0u;
+ #endif
+     for (;;) {
+         OT_TIC();
+         // ---- step choice: a full wave of the most advanced kind of work; else new paths; else what is left ----------------
+         uint32_t kind = MPT_OT_NONE;  // ring to pop from; NONE = primary step
++#ifdef MPT_OT_CARRY
++        if (n_carry != 0u) kind = MPT_OT_RINGS - 1u;
++        else
++#endif
+         if (cnt[MPT_OT_RING_E] >= 64u) kind = MPT_OT_RING_E;
+ #pragma unroll
+         for (int k = (int)MPT_OT_RINGS - 1; k >= (int)MPT_OT_RING_M; --k)  // the longest walks first
+@@ -641,9 +655,17 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
+ #pragma unroll
+             for (uint32_t k = 0; k < MPT_OT_RINGS; ++k)
+                 if (k == kind) c = cnt[k];
++#ifdef MPT_OT_CARRY
++            const uint32_t room = 64u - n_carry;
++            const uint32_t take = c < room ? c : room;
++            const uint32_t rk = wave_rank(~__ballot(carry));
++            valid = !carry && rk < take;
++            at = wbase + kind * MPT_WL_RING + (c - take + rk);
++#else
+             const uint32_t take = c < 64u ? c : 64u;
+             valid = lane < take;
+             at = wbase + kind * MPT_WL_RING + (c - take + lane);
++#endif
+ #pragma unroll
+             for (uint32_t k = 0; k < MPT_OT_RINGS; ++k)
+                 if (k == kind) cnt[k] = c - take;
+@@ -664,7 +686,11 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
+                 }
+             }
+             if (kind >= MPT_OT_RING_M) {  // a parked walk brings its stack along: back into this lane's LDS column
++#ifdef MPT_OT_CARRY
++                if (!valid && !carry) walk_cur = MPT_OT_DONE;
++#else
+                 if (!valid) walk_cur = MPT_OT_DONE;
++#endif
+                 const uint32_t deepest = wave_max_u32(valid ? walk_sp : 0u);
+ #pragma unroll
+                 for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
+@@ -675,6 +701,24 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
+                         st.lds[(2u * k + 1u) * 64u] = v2u{e.z, e.w};
+                     }
+                 }
++#ifdef MPT_OT_CARRY
++                if (carry) {  // (its stack column was not touched)
++                    ps.o = c_o;
++                    ps.d = c_d;
++                    ps.thr.x = c_tx;
++                    ps.thr.y = c_ty;
++                    T = c_T;
++                    W = c_W;
++                    walk_cur = c_cur;
++                    walk_sp = c_sp & 0xFFFFu;
++                    walk_lost = (c_sp & 0x40000000u) != 0u;
++                    walk_again = (c_sp & 0x80000000u) != 0u;
++                    at = c_at;
++                    valid = true;
++                }
++                carry = false;
++                n_carry = 0u;
++#endif
+             }
+         }
+         // the rest of a record is not needed by the tree walk: ring M steps load it afterwards
+@@ -749,6 +793,28 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
+             else
+                 done = ot_walk<COUNT, false, ALL_LDS>(ac, pp.scene, lds, st, ps.o, ps.d, r, walk_cur, walk_sp, T, W, tie, walk_lost,
+                                                       0xFFFFFFFFu, 0u, wc);
++#ifdef MPT_OT_CARRY
++            if (kind == MPT_OT_RINGS - 1u && !exhausted) {
++                const bool unf = walking && !tie && !done;
++                const uint32_t nu = (uint32_t)__popcll(__ballot(unf));
++                if (nu != 0u && cnt[MPT_OT_RINGS - 1u] + nu >= 64u) {
++                    carry = unf;
++                    n_carry = nu;
++                    if (unf) {
++                        c_o = ps.o;
++                        c_d = ps.d;
++                        c_tx = ps.thr.x;
++                        c_ty = ps.thr.y;
++                        c_T = T;
++                        c_W = W;
++                        c_cur = walk_cur;
++                        c_sp = walk_sp | (walk_lost ? 0x40000000u : 0u) | (walk_again ? 0x80000000u : 0u);
++                        c_at = at;
++                        walking = false;
++                    }
++                }
++            }
++#endif
+             if (walking) {
+                 if (kind == walk_kind) load_rest();   // (a step of ring M; an in-place walk has everything in registers)
+                 if (tie) dest = MPT_OT_RING_E;   // (whatever is left of the walk does not matter then)
+#endif
