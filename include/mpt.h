@@ -55,12 +55,16 @@ typedef struct mpt_uniforms {
 enum { MPT_RNG_LITERAL = 0,  /* bit-faithful to the reference's stuck PCG stream      */
        MPT_RNG_PHILOX = 1 }; /* Philox4x32-10, counter (pixel, sample, bounce, 0): the benchmark RNG  */
 enum { MPT_BSDF_LAMBERT = 0, /* what rayColor executes (PathTracing.h:251-255)                        */
-       MPT_BSDF_SCATTER = 1 }; /* + mirror (materialType < 0) / dielectric (> 0 = IOR) per Scatter.h:28-40, which is
-                                  dead code in the reference.  Deliberately NOT restated from it: its Lambert branch
-                                  (Scatter.h:24-27, normal + randomFloat3 of Random.h:18-30 — diffuse surfaces keep
-                                  rayColor's own bounce, PathTracing.h:251-255, in both modes), pow(x, 5) (a multiply
-                                  chain here) and the origin of transmitted rays (p - 1e-4 n here; the reference's
-                                  + n would re-hit the surface).  DESIGN.md "RNG / math specification".            */
+       MPT_BSDF_SCATTER = 1, /* + mirror (materialType < 0) / dielectric (> 0 = IOR) per Scatter.h:28-40, which is
+                                  dead code in the reference; diffuse surfaces (materialType == 0) keep rayColor's own
+                                  bounce (PathTracing.h:251-255).  Own choices, DESIGN.md "RNG / math specification":
+                                  pow(x, 5) is a multiply chain and a transmitted ray starts at p - 1e-4 n (the
+                                  reference's + n would re-hit the surface).                                        */
+       MPT_BSDF_SCATTER_ALL = 2 }; /* scatter() for every material: as MPT_BSDF_SCATTER, and diffuse surfaces take
+                                  Scatter.h's own Lambert branch too (Scatter.h:24-27,42: normalize(normal +
+                                  normalize(randomFloat3(seed))), a point of the cube [-1,1]^3 per Random.h:18-30 —
+                                  literal RNG: three draws from a copy of the stuck seed; philox: words 0, 1, 2 of
+                                  the bounce's block)                                                               */
 enum { MPT_PIPE_WAVEFRONT = 0,  /* global SoA ray queues + wave64 ballot compaction, one kernel/bounce */
        MPT_PIPE_MEGAKERNEL = 1, /* one thread per path, whole bounce loop in registers                */
        MPT_PIPE_WAVELOCAL = 2,  /* persistent waves, wave-private ray rings + ballot compaction; pipelines 0-2 walk

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPT_LIB") or os.path.join(_PKG, "lib", "libmpt_hip.so")
 
 RNG_LITERAL, RNG_PHILOX = 0, 1
-BSDF_LAMBERT, BSDF_SCATTER = 0, 1
+BSDF_LAMBERT, BSDF_SCATTER, BSDF_SCATTER_ALL = 0, 1, 2
 PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL, PIPE_ORDERED, PIPE_AUTO = 0, 1, 2, 3, 4
 REFERENCE_ORDER_PIPELINES = (PIPE_WAVEFRONT, PIPE_MEGAKERNEL, PIPE_WAVELOCAL)  # walk the BVH in the reference's own order
 DEFAULT_PIPELINE = PIPE_AUTO  # closest-first for big scenes, reference-order wave-local below 8192 primitives

@@ -20,7 +20,7 @@ using namespace MetalCppPathTracer;
 static void usage() {
     std::puts(
         "mpt_render --scene scene.xml [--asset-root DIR] [--width 1280] [--height 720]\n"
-        "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter]\n"
+        "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter|scatter-all]\n"
         "           [--pipeline auto|ordered|wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
         "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
         "           [--gpus N] [--camera-path FILE [--out-dir runs]] [--bvh reference|binned|gpu|auto]\n"
@@ -238,7 +238,10 @@ int main(int argc, char** argv) {
         }
         else if (a == "--vfov") vfov = static_cast<float>(std::atof(next()));
         else if (a == "--rng") prm.rng_mode = std::strcmp(next(), "literal") == 0 ? MPT_RNG_LITERAL : MPT_RNG_PHILOX;
-        else if (a == "--bsdf") prm.bsdf_mode = std::strcmp(next(), "scatter") == 0 ? MPT_BSDF_SCATTER : MPT_BSDF_LAMBERT;
+        else if (a == "--bsdf") {
+            const char* v = next();
+            prm.bsdf_mode = std::strcmp(v, "scatter") == 0 ? MPT_BSDF_SCATTER : std::strcmp(v, "scatter-all") == 0 ? MPT_BSDF_SCATTER_ALL : MPT_BSDF_LAMBERT;
+        }
         else if (a == "--pipeline") {
             const char* v = next();
             prm.pipeline = std::strcmp(v, "megakernel") == 0 ? MPT_PIPE_MEGAKERNEL

@@ -21,6 +21,9 @@
 namespace mpt_devbuild {
 using mpt_lbvh::Radix;
 using mpt_lbvh::Scratch;
+using mpt_sah::SahState;
+using mpt_sah::empty4;
+using mpt_sah::half_area4;
 
 struct Scalars {             // device-side results the host reads back once, at the end
     uint32_t n_spheres;      // spheres found (the first 32 positions are recorded)
@@ -199,33 +202,6 @@ __global__ void k_emit_threaded(uint32_t n_out, int n, const uint32_t* order, co
 // the items are partitioned into the other of two index arrays.  The first levels are few long tasks (the root: one wave over
 // all leaves, ~1.5 ms for 500 k), the later ones many short ones; ~25 launches in all.  Leaves = the reference leaves
 // (k_leaves: own boxes, sphere-free); node ids 2n - 1 + k are this tree's inner nodes.
-struct SahTask {
-    uint32_t b, e;     // items [b, e) of the current index array
-    int parent;        // inner node that waits for this sub-tree (-1: the root)
-    uint32_t side;
-};
-#ifndef MPT_SAH_BIG
-#define MPT_SAH_BIG 2048u   // tasks of at least this many items get a whole workgroup (k_sah_level_big), smaller ones a wave
-#endif
-struct SahState {
-    uint32_t n_next;      // tasks pushed for the next level (small ones: a wave each)
-    uint32_t n_next_big;  // ... and the big ones
-    uint32_t n_nodes;  // inner nodes created
-    int root;          // -1: no items
-    uint32_t n_items;
-};
-__device__ __forceinline__ float half_area4(float4 lo, float4 hi) {
-    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-    return dx * dy + dy * dz + dz * dx;
-}
-__device__ __forceinline__ bool empty4(float4 lo, float4 hi) { return !(hi.x >= lo.x && hi.y >= lo.y && hi.z >= lo.z); }
-__device__ __forceinline__ float axis_of(float4 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
-__device__ __forceinline__ int f2o(float f) {  // order-preserving float -> int
-    const int i = __float_as_int(f);
-    return i >= 0 ? i : i ^ 0x7FFFFFFF;
-}
-__device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
-
 // Items of the own tree = the leaves whose own box is not empty, numbered by the position of their first primitive.
 __global__ void k_item_flags(int n, const int2* range, const uint32_t* is_leaf, const float4* olo, const float4* ohi, uint32_t* flag_pos /* [n + 1] */) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,345 +219,44 @@ __global__ void k_items(int n, const int2* range, const uint32_t* is_leaf, const
     it_lo[i] = make_float4(l.x, l.y, l.z, __int_as_float(node));
     it_hi[i] = make_float4(h.x, h.y, h.z, __int_as_float(span_of(range, n, node)));
 }
-__global__ void k_sah_init(const uint32_t* rank, int n, SahState* st, SahTask* tasks, SahTask* big_tasks) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t m = rank[n];
-    st->n_items = m;
-    st->n_nodes = 0u;
-    st->root = -1;
-    st->n_next = 0u;
-    st->n_next_big = 0u;
-    if (m >= MPT_SAH_BIG) {
-        big_tasks[0] = SahTask{0u, m, -1, 0u};
-        st->n_next_big = 1u;
-    } else if (m != 0u) {
-        tasks[0] = SahTask{0u, m, -1, 0u};
-        st->n_next = 1u;
-    }
-}
-#define MPT_SAH_WAVES 4   // per workgroup
-__device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int parent, uint32_t side, int id) {
-    if (parent < 0) st->root = id;
-    else if (side == 0u) s_child[parent].x = id;
-    else s_child[parent].y = id;
-}
-// a finished split: a single item is attached at once, anything larger becomes a task of the next level
-__device__ __forceinline__ void sah_push_children(SahState* st, int2* s_child, SahTask* next, SahTask* next_big, uint32_t b, uint32_t e, uint32_t nlft,
-                                                  uint32_t k, int one_left, int one_right) {
-    const uint32_t mid = b + nlft, nrgt = e - mid;
-    if (nlft == 1u) s_child[k].x = one_left;
-    else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = SahTask{b, mid, (int)k, 0u};
-    else next[atomicAdd(&st->n_next, 1u)] = SahTask{b, mid, (int)k, 0u};
-    if (nrgt == 1u) s_child[k].y = one_right;
-    else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = SahTask{mid, e, (int)k, 1u};
-    else next[atomicAdd(&st->n_next, 1u)] = SahTask{mid, e, (int)k, 1u};
-}
-__global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi,
-                                                                  const SahTask* tasks, uint32_t n_tasks, SahTask* next, SahTask* next_big, SahState* st,
-                                                                  int2* s_child, float4* s_lo, float4* s_hi) {
-    __shared__ int bins[MPT_SAH_WAVES][3][16][7];   // per wave: (lo xyz, hi xyz as ordered ints, primitive count) per axis and bin
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x * MPT_SAH_WAVES + wv;
-    if (t >= n_tasks) return;
-    const int TOP = 2 * n - 1;
-    const SahTask task = tasks[t];
-    const uint32_t b = task.b, e = task.e, m = e - b;
-    if (m == 1u) {   // (only the root task of a one-leaf tree comes here: children of one item are attached when they are split off)
-        if (lane == 0) sah_attach(st, s_child, task.parent, task.side, __float_as_int(in_lo[b].w));
-        return;
-    }
-    if (m == 2u) {   // two items: the node, nothing to choose (a third of all tasks, at the bottom of the tree)
-        if (lane == 0) {
-            const float4 l0 = in_lo[b], h0 = in_hi[b], l1 = in_lo[b + 1u], h1 = in_hi[b + 1u];
-            const uint32_t k2 = atomicAdd(&st->n_nodes, 1u);
-            s_lo[k2] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
-            s_hi[k2] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
-            s_child[k2] = make_int2(__float_as_int(l0.w), __float_as_int(l1.w));
-            sah_attach(st, s_child, task.parent, task.side, TOP + (int)k2);
+// With the "sah" builder the binary tree under the reference-format arrays IS a binned-SAH tree over the primitives, and its
+// nodes above the leaves are the own tree's binary tree already: no second SAH.  What differs is the boxes (the own box of a
+// leaf leaves its spheres out, and may be empty) — so one bottom-up pass from the leaves refits them, and splices out what is
+// empty: eff[node] = the node that stands for the sub-tree (the leaf; TOP + node for an inner node with two non-empty
+// children; the other child's eff when one is empty; -1 when both are).
+__global__ void k_own_tree(int n, const int* parent, const int2* child, const uint32_t* is_leaf, const float4* olo, const float4* ohi, int* eff, float4* s_lo,
+                           float4* s_hi, int2* s_child, int* arrived, SahState* st) {
+    const int leaf = blockIdx.x * blockDim.x + threadIdx.x, TOP = 2 * n - 1;
+    if (leaf >= TOP || !is_leaf[leaf]) return;
+    eff[leaf] = empty4(olo[leaf], ohi[leaf]) ? -1 : leaf;
+    __threadfence();
+    int cur = leaf;
+    for (;;) {
+        const int p = parent[cur];
+        if (p < 0) {
+            st->root = __hip_atomic_load(&eff[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
-        return;
-    }
-    // pass 1: the node's box and the bounds of the box centres
-    float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
-          ch[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = b + lane; i < e; i += 64u) {
-        const float4 l = in_lo[i], h = in_hi[i];
-        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
-        for (int a = 0; a < 3; ++a) {
-            nl[a] = fminf(nl[a], lo3[a]);
-            nh[a] = fmaxf(nh[a], hi3[a]);
-            const float c = 0.5f * (lo3[a] + hi3[a]);
-            cl[a] = fminf(cl[a], c);
-            ch[a] = fmaxf(ch[a], c);
+        if (atomicAdd(&arrived[p], 1) == 0) return;   // the sibling sub-tree is not finished yet
+        __threadfence();
+        const int2 c = child[p];
+        // (written by other CUs: agent-scope loads)
+        const int ex = __hip_atomic_load(&eff[c.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ey = __hip_atomic_load(&eff[c.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int e = -1;
+        if (ex >= 0 && ey >= 0) {
+            const float4 a0 = ex < TOP ? olo[ex] : mpt_lbvh::ld4(s_lo + (ex - TOP)), a1 = ex < TOP ? ohi[ex] : mpt_lbvh::ld4(s_hi + (ex - TOP));
+            const float4 b0 = ey < TOP ? olo[ey] : mpt_lbvh::ld4(s_lo + (ey - TOP)), b1 = ey < TOP ? ohi[ey] : mpt_lbvh::ld4(s_hi + (ey - TOP));
+            s_lo[p] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.0f);
+            s_hi[p] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.0f);
+            s_child[p] = make_int2(ex, ey);
+            e = TOP + p;
+        } else {
+            e = ex >= 0 ? ex : ey;
         }
+        eff[p] = e;
+        __threadfence();
+        cur = p;
     }
-    for (int off = 32; off > 0; off >>= 1)
-        for (int a = 0; a < 3; ++a) {
-            nl[a] = fminf(nl[a], __shfl_xor(nl[a], off));
-            nh[a] = fmaxf(nh[a], __shfl_xor(nh[a], off));
-            cl[a] = fminf(cl[a], __shfl_xor(cl[a], off));
-            ch[a] = fmaxf(ch[a], __shfl_xor(ch[a], off));
-        }
-    uint32_t k = 0;
-    if (lane == 0) {
-        k = atomicAdd(&st->n_nodes, 1u);
-        s_lo[k] = make_float4(nl[0], nl[1], nl[2], 0.0f);
-        s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
-        sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
-    }
-    k = (uint32_t)__shfl((int)k, 0);
-    // pass 2: bins
-    for (uint32_t q = lane; q < 3u * 16u * 7u; q += 64u) {
-        const uint32_t f = q % 7u;
-        (&bins[wv][0][0][0])[q] = f < 3u ? 0x7FFFFFFF : f < 6u ? (int)0x80000000 : 0;
-    }
-    __builtin_amdgcn_wave_barrier();
-    float inv[3];
-    for (int a = 0; a < 3; ++a) {
-        const float ext = ch[a] - cl[a];
-        inv[a] = ext > 0.0f && isfinite(ext) ? 16.0f / ext : 0.0f;
-    }
-    // (a node of more than 256 items is binned from an evenly spaced sample of ~256 of them: the 21 LDS atomics per item are
-    //  what this pass costs, and 256 boxes choose among 45 planes as well as 100,000 do; box and partition stay exact)
-    const uint32_t step = m > 256u ? m / 256u : 1u;
-    for (uint32_t i = b + lane * step; i < e; i += 64u * step) {
-        const float4 l = in_lo[i], h = in_hi[i];
-        const int cnt = __float_as_int(h.w);
-        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
-        for (int a = 0; a < 3; ++a) {
-            if (inv[a] == 0.0f) continue;
-            int q = (int)((0.5f * (lo3[a] + hi3[a]) - cl[a]) * inv[a]);
-            q = q < 0 ? 0 : (q > 15 ? 15 : q);
-            int* B = bins[wv][a][q];
-            atomicMin(&B[0], f2o(l.x)); atomicMin(&B[1], f2o(l.y)); atomicMin(&B[2], f2o(l.z));
-            atomicMax(&B[3], f2o(h.x)); atomicMax(&B[4], f2o(h.y)); atomicMax(&B[5], f2o(h.z));
-            atomicAdd(&B[6], cnt);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    // pass 3: lane = (axis, split after bin s): cost = area(L) * count(L) + area(R) * count(R)
-    float cost = INFINITY;
-    if (lane < 45u) {
-        const int a = (int)(lane / 15u), sp = (int)(lane % 15u);
-        if (inv[a] != 0.0f) {
-            float L[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, R[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            int cL = 0, cR = 0;
-            for (int q = 0; q < 16; ++q) {
-                const int* B = bins[wv][a][q];
-                if (B[6] == 0) continue;
-                float* D = q <= sp ? L : R;
-                for (int c = 0; c < 3; ++c) {
-                    D[c] = fminf(D[c], o2f(B[c]));
-                    D[3 + c] = fmaxf(D[3 + c], o2f(B[3 + c]));
-                }
-                if (q <= sp) cL += B[6];
-                else cR += B[6];
-            }
-            if (cL != 0 && cR != 0)
-                cost = half_area4(make_float4(L[0], L[1], L[2], 0), make_float4(L[3], L[4], L[5], 0)) * (float)cL +
-                       half_area4(make_float4(R[0], R[1], R[2], 0), make_float4(R[3], R[4], R[5], 0)) * (float)cR;
-        }
-    }
-    float best = cost;
-    for (int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_xor(best, off));
-    const unsigned long long who = __ballot(cost == best && best < INFINITY);
-    const int pick = who != 0ull ? (int)__ffsll((long long)who) - 1 : -1;   // ties: the lowest (axis, split)
-    const int paxis = pick >= 0 ? pick / 15 : 0, psplit = pick >= 0 ? pick % 15 : 0;
-    // partition into the other array: left from b upwards, right from e - 1 downwards
-    uint32_t nlft = 0, nrgt = 0;
-    int one_left = 0, one_right = 0;   // (the first item that went to either side: THE item if it stays alone)
-    for (uint32_t base = b; base < e; base += 64u) {
-        const uint32_t i = base + lane;
-        const bool valid = i < e;
-        float4 l = make_float4(0, 0, 0, 0), h = l;
-        bool left = false;
-        if (valid) {
-            l = in_lo[i];
-            h = in_hi[i];
-            if (pick >= 0) {
-                int q = (int)((0.5f * (axis_of(l, paxis) + axis_of(h, paxis)) - cl[paxis]) * inv[paxis]);
-                q = q < 0 ? 0 : (q > 15 ? 15 : q);
-                left = q <= psplit;
-            } else {
-                left = i - b < m / 2u;   // no plane separates the box centres: halves
-            }
-        }
-        const unsigned long long lm = __ballot(valid && left), rm = __ballot(valid && !left);
-        if (valid) {
-            const uint32_t dst = left ? b + nlft + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))
-                                      : e - 1u - nrgt - (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
-            out_lo[dst] = l;
-            out_hi[dst] = h;
-        }
-        if (nlft == 0u && lm != 0ull) one_left = __shfl(__float_as_int(l.w), __ffsll((long long)lm) - 1);
-        if (nrgt == 0u && rm != 0ull) one_right = __shfl(__float_as_int(l.w), __ffsll((long long)rm) - 1);
-        nlft += (uint32_t)__popcll(lm);
-        nrgt += (uint32_t)__popcll(rm);
-    }
-    if (lane == 0) sah_push_children(st, s_child, next, next_big, b, e, nlft, k, one_left, one_right);
-}
-
-// The same for a BIG task, by a whole workgroup of 1024 threads (the root of a 500 k-leaf tree: 1.5 ms instead of 70): bins
-// shared in LDS, the partition chunk by chunk with a prefix over the waves' ballots (deterministic item order).
-#define MPT_SAH_BIG_THREADS 1024
-__global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_sah_level_big(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi,
-                                                                      const SahTask* tasks, SahTask* next, SahTask* next_big, SahState* st, int2* s_child,
-                                                                      float4* s_lo, float4* s_hi) {
-    __shared__ int bounds[12];          // node box lo/hi, centre bounds lo/hi (ordered ints)
-    __shared__ int bins[3][16][7];
-    __shared__ float s_cost[48];
-    __shared__ uint32_t s_wl[16], s_wr[16], s_k;
-    __shared__ int s_one[2];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const int TOP = 2 * n - 1;
-    const SahTask task = tasks[blockIdx.x];
-    const uint32_t b = task.b, e = task.e, m = e - b;
-    if (tid < 12u) bounds[tid] = tid % 6u < 3u ? 0x7FFFFFFF : (int)0x80000000;
-    for (uint32_t q = tid; q < 3u * 16u * 7u; q += MPT_SAH_BIG_THREADS) {
-        const uint32_t f = q % 7u;
-        (&bins[0][0][0])[q] = f < 3u ? 0x7FFFFFFF : f < 6u ? (int)0x80000000 : 0;
-    }
-    __syncthreads();
-    // pass 1
-    {
-        float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
-              ch[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t i = b + tid; i < e; i += MPT_SAH_BIG_THREADS) {
-            const float4 l = in_lo[i], h = in_hi[i];
-            const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
-            for (int a = 0; a < 3; ++a) {
-                nl[a] = fminf(nl[a], lo3[a]);
-                nh[a] = fmaxf(nh[a], hi3[a]);
-                const float c = 0.5f * (lo3[a] + hi3[a]);
-                cl[a] = fminf(cl[a], c);
-                ch[a] = fmaxf(ch[a], c);
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1)
-            for (int a = 0; a < 3; ++a) {
-                nl[a] = fminf(nl[a], __shfl_xor(nl[a], off));
-                nh[a] = fmaxf(nh[a], __shfl_xor(nh[a], off));
-                cl[a] = fminf(cl[a], __shfl_xor(cl[a], off));
-                ch[a] = fmaxf(ch[a], __shfl_xor(ch[a], off));
-            }
-        if (lane == 0)
-            for (int a = 0; a < 3; ++a) {
-                atomicMin(&bounds[a], f2o(nl[a]));
-                atomicMax(&bounds[3 + a], f2o(nh[a]));
-                atomicMin(&bounds[6 + a], f2o(cl[a]));
-                atomicMax(&bounds[9 + a], f2o(ch[a]));
-            }
-    }
-    __syncthreads();
-    float cl[3], inv[3];
-    for (int a = 0; a < 3; ++a) {
-        cl[a] = o2f(bounds[6 + a]);
-        const float ext = o2f(bounds[9 + a]) - cl[a];
-        inv[a] = ext > 0.0f && isfinite(ext) ? 16.0f / ext : 0.0f;
-    }
-    if (tid == 0) {
-        const uint32_t k = atomicAdd(&st->n_nodes, 1u);
-        s_k = k;
-        s_lo[k] = make_float4(o2f(bounds[0]), o2f(bounds[1]), o2f(bounds[2]), 0.0f);
-        s_hi[k] = make_float4(o2f(bounds[3]), o2f(bounds[4]), o2f(bounds[5]), 0.0f);
-        sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
-    }
-    // pass 2
-    const uint32_t step = m > 4096u ? m / 4096u : 1u;   // (binned from a sample of ~4096 items: see k_sah_level)
-    for (uint32_t i = b + tid * step; i < e; i += MPT_SAH_BIG_THREADS * step) {
-        const float4 l = in_lo[i], h = in_hi[i];
-        const int cnt = __float_as_int(h.w);
-        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
-        for (int a = 0; a < 3; ++a) {
-            if (inv[a] == 0.0f) continue;
-            int q = (int)((0.5f * (lo3[a] + hi3[a]) - cl[a]) * inv[a]);
-            q = q < 0 ? 0 : (q > 15 ? 15 : q);
-            int* B = bins[a][q];
-            atomicMin(&B[0], f2o(l.x)); atomicMin(&B[1], f2o(l.y)); atomicMin(&B[2], f2o(l.z));
-            atomicMax(&B[3], f2o(h.x)); atomicMax(&B[4], f2o(h.y)); atomicMax(&B[5], f2o(h.z));
-            atomicAdd(&B[6], cnt);
-        }
-    }
-    __syncthreads();
-    // pass 3
-    if (tid < 48u) {
-        float cost = INFINITY;
-        if (tid < 45u) {
-            const int a = (int)(tid / 15u), sp = (int)(tid % 15u);
-            if (inv[a] != 0.0f) {
-                float L[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, R[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                int cL = 0, cR = 0;
-                for (int q = 0; q < 16; ++q) {
-                    const int* B = bins[a][q];
-                    if (B[6] == 0) continue;
-                    float* D = q <= sp ? L : R;
-                    for (int c = 0; c < 3; ++c) {
-                        D[c] = fminf(D[c], o2f(B[c]));
-                        D[3 + c] = fmaxf(D[3 + c], o2f(B[3 + c]));
-                    }
-                    if (q <= sp) cL += B[6];
-                    else cR += B[6];
-                }
-                if (cL != 0 && cR != 0)
-                    cost = half_area4(make_float4(L[0], L[1], L[2], 0), make_float4(L[3], L[4], L[5], 0)) * (float)cL +
-                           half_area4(make_float4(R[0], R[1], R[2], 0), make_float4(R[3], R[4], R[5], 0)) * (float)cR;
-            }
-        }
-        s_cost[tid] = cost;
-    }
-    if (tid < 2u) s_one[tid] = 0;
-    __syncthreads();
-    int pick = -1;
-    {
-        float best = INFINITY;
-        for (int q = 0; q < 45; ++q)
-            if (s_cost[q] < best) best = s_cost[q], pick = q;   // ties: the lowest (axis, split), as in the wave kernel
-    }
-    const int paxis = pick >= 0 ? pick / 15 : 0, psplit = pick >= 0 ? pick % 15 : 0;
-    // partition, chunk by chunk
-    uint32_t nlft = 0, nrgt = 0;   // (uniform: running totals)
-    for (uint32_t base = b; base < e; base += MPT_SAH_BIG_THREADS) {
-        const uint32_t i = base + tid;
-        const bool valid = i < e;
-        float4 l = make_float4(0, 0, 0, 0), h = l;
-        bool left = false;
-        if (valid) {
-            l = in_lo[i];
-            h = in_hi[i];
-            if (pick >= 0) {
-                int q = (int)((0.5f * (axis_of(l, paxis) + axis_of(h, paxis)) - cl[paxis]) * inv[paxis]);
-                q = q < 0 ? 0 : (q > 15 ? 15 : q);
-                left = q <= psplit;
-            } else {
-                left = i - b < m / 2u;
-            }
-        }
-        const unsigned long long lm = __ballot(valid && left), rm = __ballot(valid && !left);
-        if (lane == 0) {
-            s_wl[wv] = (uint32_t)__popcll(lm);
-            s_wr[wv] = (uint32_t)__popcll(rm);
-        }
-        __syncthreads();
-        uint32_t pl = 0, pr = 0, tl = 0, tr = 0;
-        for (uint32_t w = 0; w < 16u; ++w) {
-            if (w < wv) pl += s_wl[w], pr += s_wr[w];
-            tl += s_wl[w];
-            tr += s_wr[w];
-        }
-        if (valid) {
-            const uint32_t dst = left ? b + nlft + pl + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))
-                                      : e - 1u - nrgt - pr - (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
-            out_lo[dst] = l;
-            out_hi[dst] = h;
-        }
-        if (nlft == 0u && tl != 0u && lm != 0ull && pl == 0u && lane == (uint32_t)(__ffsll((long long)lm) - 1)) s_one[0] = __float_as_int(l.w);
-        if (nrgt == 0u && tr != 0u && rm != 0ull && pr == 0u && lane == (uint32_t)(__ffsll((long long)rm) - 1)) s_one[1] = __float_as_int(l.w);
-        nlft += tl;
-        nrgt += tr;
-        __syncthreads();
-    }
-    if (tid == 0) sah_push_children(st, s_child, next, next_big, b, e, nlft, s_k, s_one[0], s_one[1]);
 }
 
 // ---- the own 4-wide tree: breadth-first collapse of the SAH tree, level by level -----------------------------------------------
@@ -712,8 +387,10 @@ struct Built {
     }
 };
 
-static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, bool use_ploc, uint32_t n_spheres_hint, Built& out) {
-    Scratch sc;
+static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint, Built& out,
+                        mpt_lbvh::ScratchPool* pool = nullptr) {
+    Scratch sc(pool);
+    MPT_LB(sc.reserve((size_t)n * 720 + ((size_t)8 << 20)));   // (measured: ~620 bytes per primitive)
     Radix R;
     Scalars* d_sc;
     struct Pinned {   // read-backs of a few words per level go through pinned memory (a pageable target costs ~0.3 ms per copy)
@@ -755,7 +432,7 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
                            mat_of_prim, mtable, d_sc);
     }
     // the binary tree
-    MPT_LB(mpt_lbvh::build_radix(stream, sc, d_prims_in, n, leaf_max, use_ploc, R));
+    MPT_LB(mpt_lbvh::build_radix(stream, sc, d_prims_in, n, leaf_max, builder, R));
     const uint32_t n_out = R.n_out;
     const size_t nn = 2 * (size_t)n - 1;
     const uint32_t gnn = (uint32_t)((nn + B - 1) / B), go = (n_out + B - 1) / B;
@@ -806,64 +483,46 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     MPT_LB(hipMalloc(&out.nodes, (size_t)n_out * 32));
     hipLaunchKernelGGL(k_emit_threaded, dim3(go), dim3(B), 0, stream, n_out, (int)n, (const uint32_t*)order, (const uint32_t*)tpos, (const uint32_t*)is_leaf,
                        (const int2*)R.child, (const int2*)R.range, (const int*)skip, (const float4*)R.nlo, (const float4*)R.nhi, out.nodes);
-    // own tree: binned SAH over the leaves (a wave or a workgroup per node, one launch pair per level), then the 4-wide collapse
-    uint32_t *flag_pos, *rank;
-    float4 *it_lo_a, *it_hi_a, *it_lo_b, *it_hi_b;
-    SahState* d_st;
+    // own tree: its binary tree (the builder's own SAH tree refitted, or a binned SAH over the leaves: mpt_sah.h), then the 4-wide collapse
     const uint32_t max_items = n_out;   // (leaves <= output nodes)
-    MPT_LB(sc.alloc(&flag_pos, (size_t)n + 1));
-    MPT_LB(sc.alloc(&rank, (size_t)n + 1));
-    MPT_LB(sc.alloc(&d_st, 1));
-    MPT_LB(sc.alloc(&it_lo_a, max_items));
-    MPT_LB(sc.alloc(&it_hi_a, max_items));
-    MPT_LB(sc.alloc(&it_lo_b, max_items));
-    MPT_LB(sc.alloc(&it_hi_b, max_items));
-    SahTask *tasks_a, *tasks_b, *big_a, *big_b;
+    SahState* d_st;
     int2* s_child;
     float4 *s_lo, *s_hi;
-    MPT_LB(sc.alloc(&tasks_a, max_items + 2));
-    MPT_LB(sc.alloc(&tasks_b, max_items + 2));
-    MPT_LB(sc.alloc(&big_a, max_items / MPT_SAH_BIG + 2));
-    MPT_LB(sc.alloc(&big_b, max_items / MPT_SAH_BIG + 2));
-    MPT_LB(sc.alloc(&s_child, max_items));
-    MPT_LB(sc.alloc(&s_lo, max_items));
-    MPT_LB(sc.alloc(&s_hi, max_items));
-    MPT_LB(hipMemsetAsync(flag_pos, 0, ((size_t)n + 1) * 4, stream));
-    hipLaunchKernelGGL(k_item_flags, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)R.range, (const uint32_t*)is_leaf, (const float4*)olo, (const float4*)ohi, flag_pos);
-    {
+    if (builder == mpt_lbvh::BUILDER_SAH && n > 2) {
+        int *eff, *arrived;
+        MPT_LB(sc.alloc(&d_st, 1));
+        MPT_LB(sc.alloc(&eff, nn));
+        MPT_LB(sc.alloc(&arrived, nn));
+        MPT_LB(sc.alloc(&s_child, n));
+        MPT_LB(sc.alloc(&s_lo, n));
+        MPT_LB(sc.alloc(&s_hi, n));
+        MPT_LB(hipMemsetAsync(arrived, 0, nn * 4, stream));
+        MPT_LB(hipMemsetAsync(d_st, 0xFF, sizeof(SahState), stream));   // root = -1
+        hipLaunchKernelGGL(k_own_tree, dim3(gnn), dim3(B), 0, stream, (int)n, (const int*)R.parent, (const int2*)R.child, (const uint32_t*)is_leaf, (const float4*)olo,
+                           (const float4*)ohi, eff, s_lo, s_hi, s_child, arrived, d_st);
+    } else {
+        uint32_t *flag_pos, *rank;
+        float4 *it_lo_a, *it_hi_a;
+        MPT_LB(sc.alloc(&flag_pos, (size_t)n + 1));
+        MPT_LB(sc.alloc(&rank, (size_t)n + 1));
+        MPT_LB(sc.alloc(&it_lo_a, max_items));
+        MPT_LB(sc.alloc(&it_hi_a, max_items));
+        MPT_LB(hipMemsetAsync(flag_pos, 0, ((size_t)n + 1) * 4, stream));
+        hipLaunchKernelGGL(k_item_flags, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)R.range, (const uint32_t*)is_leaf, (const float4*)olo, (const float4*)ohi,
+                           flag_pos);
         size_t sb = 0;
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, flag_pos, rank, (int)n + 1, stream));
         char* tmp;
         MPT_LB(sc.alloc(&tmp, sb));
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp, sb, flag_pos, rank, (int)n + 1, stream));
-    }
-    hipLaunchKernelGGL(k_items, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)R.range, (const uint32_t*)is_leaf, (const float4*)olo, (const float4*)ohi,
-                       (const uint32_t*)rank, it_lo_a, it_hi_a);
-    hipLaunchKernelGGL(k_sah_init, dim3(1), dim3(64), 0, stream, (const uint32_t*)rank, (int)n, d_st, tasks_a, big_a);
-    {
-        SahState& h = *(SahState*)pin;
-        MPT_LB(hipMemcpyAsync(&h, d_st, sizeof h, hipMemcpyDeviceToHost, stream));
-        MPT_LB(hipStreamSynchronize(stream));
-        uint32_t n_tasks = h.n_next, n_big = h.n_next_big;
-        for (int level = 0; level < 4096 && (n_tasks | n_big) != 0u; ++level) {
-            MPT_LB(hipMemsetAsync(&d_st->n_next, 0, 8, stream));   // n_next, n_next_big
-            if (n_big)
-                hipLaunchKernelGGL(k_sah_level_big, dim3(n_big), dim3(MPT_SAH_BIG_THREADS), 0, stream, (int)n, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b,
-                                   it_hi_b, (const SahTask*)big_a, tasks_b, big_b, d_st, s_child, s_lo, s_hi);
-            if (n_tasks)
-                hipLaunchKernelGGL(k_sah_level, dim3((n_tasks + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES), dim3(64 * MPT_SAH_WAVES), 0, stream, (int)n,
-                                   (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, n_tasks, tasks_b, big_b, d_st,
-                                   s_child, s_lo, s_hi);
-            MPT_LB(hipMemcpyAsync(&h, d_st, sizeof h, hipMemcpyDeviceToHost, stream));
-            MPT_LB(hipStreamSynchronize(stream));
-            n_tasks = h.n_next;
-            n_big = h.n_next_big;
-            std::swap(tasks_a, tasks_b);
-            std::swap(big_a, big_b);
-            std::swap(it_lo_a, it_lo_b);
-            std::swap(it_hi_a, it_hi_b);
-        }
-        if ((n_tasks | n_big) != 0u) return hipErrorUnknown;
+        hipLaunchKernelGGL(k_items, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)R.range, (const uint32_t*)is_leaf, (const float4*)olo, (const float4*)ohi,
+                           (const uint32_t*)rank, it_lo_a, it_hi_a);
+        mpt_sah::SahTree T;
+        MPT_LB(mpt_sah::run_sah(stream, sc, pin, (int)(2 * n - 1), (const uint32_t*)(rank + n), 0u, max_items, it_lo_a, it_hi_a, T));
+        d_st = T.st;
+        s_child = T.child;
+        s_lo = T.lo;
+        s_hi = T.hi;
     }
     const uint32_t cap = max_items + 2u;   // wide nodes <= inner nodes of the SAH tree (+ the root of a one-leaf tree)
     uint32_t *wbin, *c_nint, *c_offs;

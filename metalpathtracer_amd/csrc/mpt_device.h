@@ -543,7 +543,20 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, LdsNodes lds, c
     F3 ruv = random_unit_vector(sp, rnd);
     F3 nd;
     bool through = false;
-    if (sp.bsdf_mode == 0 || mtype == 0.0f) {
+    if (sp.bsdf_mode == 2 && mtype == 0.0f) {  // Scatter.h:24-27,42 with randomFloat3 of Random.h:18-30 (dead in the reference)
+        F3 c;
+        if (sp.rng_mode == 0) {
+            uint32_t s = g.lit_seed;
+            c.x = pcg_float(s) * 2.0f - 1.0f;
+            s = pcg_hash(s);
+            c.y = pcg_float(s) * 2.0f - 1.0f;
+            s = pcg_hash(s);
+            c.z = pcg_float(s) * 2.0f - 1.0f;
+        } else {  // (word 2 of the block is the Fresnel number of a dielectric bounce: never both in one bounce)
+            c = f3(rnd.uz * 2.0f - 1.0f, rnd.uphi * 2.0f - 1.0f, u_extra * 2.0f - 1.0f);
+        }
+        nd = normalize3(h.normal + normalize3(c));
+    } else if (sp.bsdf_mode == 0 || mtype == 0.0f) {
         nd = normalize3(h.normal + ruv);  // PathTracing.h:252-254
     } else if (mtype < 0.0f) {            // Scatter.h:28-31
         nd = normalize3(reflect3(ps.d, h.normal));

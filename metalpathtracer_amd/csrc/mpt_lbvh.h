@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <vector>
 
+#include "mpt_sah.h"
+
 #define MPT_LBVH_LEAF_MAX 8u   // what the reference's builder allows (R/Scene/Scene.h:223) and a device leaf record holds twice over
 
 namespace mpt_lbvh {
@@ -293,44 +295,66 @@ __global__ void k_ploc_first(int n, const int2* child, const int* parent, const 
         if (y == child[p].y) f += size[child[p].x];
     first[node] = f;
 }
-// renumber: internal id k (creation order, root last) -> (n-2) - k (root 0); leaf (n-1) + m -> (n-1) + first
-__device__ __forceinline__ int ploc_new_id(int n, int id, const uint32_t* first) { return id < n - 1 ? (n - 2) - id : (n - 1) + (int)first[id]; }
+// renumber: leaf (n-1) + m -> (n-1) + first.  Internal id k -> (n-2) - k when the tree was made bottom-up (creation order, the
+// root last).  The top-down builder numbers its nodes by atomics, in no reproducible order: there an inner node takes the
+// position of the gap between two primitives that it splits at (first + primitives of its left child - 1: one gap per inner
+// node), with the root's number and 0 exchanged — the same tree gets the same numbers on every run.  Node 0 is the root either way.
+template <bool TOP_DOWN>
+__device__ __forceinline__ int ploc_new_id(int n, int id, const uint32_t* first, const int2* child, const uint32_t* size) {
+    if (id >= n - 1) return (n - 1) + (int)first[id];
+    if (!TOP_DOWN) return (n - 2) - id;
+    const int s = (int)(first[id] + size[child[id].x]) - 1, r = (int)size[child[0].x] - 1;
+    return s == r ? 0 : (s == 0 ? r : s);
+}
+template <bool TOP_DOWN>
 __global__ void k_ploc_renumber(int n, const int2* child, const int* parent, const uint32_t* size, const uint32_t* first, const float4* nlo, const float4* nhi,
                                 const uint32_t* vals, int2* child2, int* parent2, int2* range2, float4* nlo2, float4* nhi2, uint32_t* vals2) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
     if (node >= 2 * n - 1) return;
-    const int id2 = ploc_new_id(n, node, first);
-    parent2[id2] = parent[node] < 0 ? -1 : ploc_new_id(n, parent[node], first);
+    const int id2 = ploc_new_id<TOP_DOWN>(n, node, first, child, size);
+    parent2[id2] = parent[node] < 0 ? -1 : ploc_new_id<TOP_DOWN>(n, parent[node], first, child, size);
     nlo2[id2] = nlo[node];
     nhi2[id2] = nhi[node];
     if (node < n - 1) {
-        child2[id2] = make_int2(ploc_new_id(n, child[node].x, first), ploc_new_id(n, child[node].y, first));
+        child2[id2] = make_int2(ploc_new_id<TOP_DOWN>(n, child[node].x, first, child, size), ploc_new_id<TOP_DOWN>(n, child[node].y, first, child, size));
         range2[id2] = make_int2((int)first[node], (int)(first[node] + size[node] - 1u));
     } else {
         vals2[first[node]] = vals[node - (n - 1)];
     }
 }
 
-struct Scratch {  // freed on every exit path
-    std::vector<void*> ptrs;
-    ~Scratch() {
-        for (void* p : ptrs) hipFree(p);
+// builder "sah": the primitives as items of mpt_sah.h (id = the leaf (n-1) + p, one primitive each) ...
+__global__ void k_prim_items(int n, const float4* blo, const float4* bhi, float4* it_lo, float4* it_hi, uint32_t* vals) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 l = blo[p], h = bhi[p];
+    it_lo[p] = make_float4(l.x, l.y, l.z, __int_as_float(n - 1 + p));
+    it_hi[p] = make_float4(h.x, h.y, h.z, __int_as_float(1));
+    vals[p] = (uint32_t)p;
+}
+// ... and its tree (inner node k = SAH node k, made top-down: parents before children, the root first) in the arrays the
+// clustering leaves: children, parents, primitives below every node, boxes
+__global__ void k_sah_to_radix(int n, const int2* s_child, const float4* s_lo, const float4* s_hi, const float4* blo, const float4* bhi, int2* child, int* parent,
+                               uint32_t* size, float4* nlo, float4* nhi) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x, top = 2 * n - 1;
+    if (node >= top) return;
+    if (node == 0) parent[0] = -1;
+    if (node < n - 1) {
+        const int2 c = s_child[node];
+        const int x = c.x >= top ? c.x - top : c.x, y = c.y >= top ? c.y - top : c.y;
+        child[node] = make_int2(x, y);
+        parent[x] = node;
+        parent[y] = node;
+        const float4 l = s_lo[node], h = s_hi[node];
+        size[node] = (uint32_t)__float_as_int(l.w);
+        nlo[node] = make_float4(l.x, l.y, l.z, 0.0f);
+        nhi[node] = make_float4(h.x, h.y, h.z, 0.0f);
+    } else {
+        size[node] = 1u;
+        nlo[node] = blo[node - (n - 1)];
+        nhi[node] = bhi[node - (n - 1)];
     }
-    template <class T>
-    hipError_t alloc(T** p, size_t count) {
-        void* q = nullptr;
-        hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
-        if (e == hipSuccess) ptrs.push_back(q);
-        *p = (T*)q;
-        return e;
-    }
-};
-
-#define MPT_LB(call)                       \
-    do {                                   \
-        hipError_t e_ = (call);            \
-        if (e_ != hipSuccess) return e_;   \
-    } while (0)
+}
 
 // The radix tree as it stands on the device after build_radix (all arrays owned by the Scratch passed in):
 //   node ids: internal k in [0, n-1), single primitive at sorted position p -> (n-1) + p;  2n - 1 ids in all
@@ -350,9 +374,30 @@ struct Radix {
     uint32_t n_out = 0;                      // output nodes (read back)
 };
 
+// the output nodes of a finished tree: flags, compact index, count (one stream synchronisation for the count)
+static hipError_t finish_radix(hipStream_t stream, Scratch& sc, Radix& R, uint32_t* pin) {
+    const uint32_t n = R.n;
+    const int leaf_max = R.leaf_max;
+    const size_t nn = 2 * (size_t)n - 1;
+    const uint32_t B = 256, gnn = (uint32_t)((nn + B - 1) / B);
+    hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int*)R.parent, (const int2*)R.range, R.keep);
+    size_t scan_bytes = 0;
+    MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
+    char* tmp2;
+    MPT_LB(sc.alloc(&tmp2, scan_bytes));
+    MPT_LB(hipMemsetAsync(R.keep + nn, 0, 4, stream));
+    MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
+    MPT_LB(hipGetLastError());
+    MPT_LB(hipMemcpyAsync(pin, R.index + nn, 4, hipMemcpyDeviceToHost, stream));
+    MPT_LB(hipStreamSynchronize(stream));
+    R.n_out = pin[0];
+    return hipSuccess;
+}
+
 // d_prims: device, 3 float4 per primitive.  Leaves everything of Radix on the device; synchronises the stream once to
-// read the output node count.
-static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, uint32_t n, int leaf_max, bool use_ploc, Radix& R) {
+// read the output node count (and once per round / level of the clustering or the SAH).
+enum { BUILDER_KARRAS = 0, BUILDER_PLOC = 1, BUILDER_SAH = 2 };
+static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, uint32_t n, int leaf_max, int builder, Radix& R) {
     int *arrived;
     unsigned long long *keys, *keys2;
     uint32_t *vals0, *vals_sorted;
@@ -386,13 +431,37 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
     MPT_LB(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
     const uint32_t B = 256, gn = (n + B - 1) / B, gnn = (uint32_t)((nn + B - 1) / B);
     hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, R.blo, R.bhi, R.cb);
+    if (n > 2 && builder == BUILDER_SAH) {
+        // top-down binned SAH over the primitives (mpt_sah.h), then renumbered like the clustering's tree
+        float4 *it_lo, *it_hi, *nlo0, *nhi0;
+        int2* child0;
+        int* parent0;
+        uint32_t *size, *first;
+        MPT_LB(sc.alloc(&it_lo, n));
+        MPT_LB(sc.alloc(&it_hi, n));
+        MPT_LB(sc.alloc(&child0, n));
+        MPT_LB(sc.alloc(&parent0, nn));
+        MPT_LB(sc.alloc(&nlo0, nn));
+        MPT_LB(sc.alloc(&nhi0, nn));
+        MPT_LB(sc.alloc(&size, nn));
+        MPT_LB(sc.alloc(&first, nn));
+        hipLaunchKernelGGL(k_prim_items, dim3(gn), dim3(B), 0, stream, (int)n, (const float4*)R.blo, (const float4*)R.bhi, it_lo, it_hi, vals0);
+        mpt_sah::SahTree T;
+        MPT_LB(mpt_sah::run_sah(stream, sc, pinned.p, (int)nn, nullptr, n, n, it_lo, it_hi, T));
+        hipLaunchKernelGGL(k_sah_to_radix, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)T.child, (const float4*)T.lo, (const float4*)T.hi, (const float4*)R.blo,
+                           (const float4*)R.bhi, child0, parent0, size, nlo0, nhi0);
+        hipLaunchKernelGGL(k_ploc_first, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size, first);
+        hipLaunchKernelGGL(k_ploc_renumber<true>, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size,
+                           (const uint32_t*)first, (const float4*)nlo0, (const float4*)nhi0, (const uint32_t*)vals0, R.child, R.parent, R.range, R.nlo, R.nhi, R.vals);
+        return finish_radix(stream, sc, R, pinned.p);
+    }
     hipLaunchKernelGGL(k_morton, dim3(gn), dim3(B), 0, stream, (const float4*)R.blo, (const float4*)R.bhi, n, (const int*)R.cb, keys, vals0);
     size_t tmp_bytes = 0;
     MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals0, vals_sorted, (int)n, 0, 63, stream));
     char* tmp;
     MPT_LB(sc.alloc(&tmp, tmp_bytes));
     MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals0, vals_sorted, (int)n, 0, 63, stream));
-    if (n > 2 && use_ploc) {
+    if (n > 2 && builder == BUILDER_PLOC) {
         // clustering on scratch arrays in creation order, then the renumbered tree into R's arrays
         int2 *child0;
         int *parent0;
@@ -440,7 +509,7 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
         }
         if (alive != 1u) return hipErrorUnknown;
         hipLaunchKernelGGL(k_ploc_first, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size, first);
-        hipLaunchKernelGGL(k_ploc_renumber, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size, (const uint32_t*)first,
+        hipLaunchKernelGGL(k_ploc_renumber<false>, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size, (const uint32_t*)first,
                            (const float4*)nlo0, (const float4*)nhi0, (const uint32_t*)vals_sorted, R.child, R.parent, R.range, R.nlo, R.nhi, R.vals);
     } else {
         MPT_LB(hipMemcpyAsync(R.vals, vals_sorted, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
@@ -453,18 +522,7 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
         hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, stream, (const uint32_t*)R.vals, (const float4*)R.blo, (const float4*)R.bhi, (int)n,
                            (const int2*)R.child, (const int*)R.parent, R.nlo, R.nhi, arrived);
     }
-    hipLaunchKernelGGL(k_mark, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int*)R.parent, (const int2*)R.range, R.keep);
-    size_t scan_bytes = 0;
-    MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
-    char* tmp2;
-    MPT_LB(sc.alloc(&tmp2, scan_bytes));
-    MPT_LB(hipMemsetAsync(R.keep + nn, 0, 4, stream));
-    MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, scan_bytes, R.keep, R.index, (int)nn + 1, stream));
-    MPT_LB(hipGetLastError());
-    MPT_LB(hipMemcpyAsync(pinned.p, R.index + nn, 4, hipMemcpyDeviceToHost, stream));
-    MPT_LB(hipStreamSynchronize(stream));
-    R.n_out = pinned.p[0];
-    return hipSuccess;
+    return finish_radix(stream, sc, R, pinned.p);
 }
 
 // the output tree in the reference's buffer format, on the device: d_bvh (2 float4 per output node), d_idx (n ints)
@@ -477,9 +535,10 @@ static hipError_t emit_reference_format(hipStream_t stream, const Radix& R, floa
 
 // prims: host, 12 floats per primitive (Scene::createTransformsBuffer).  bvh_out: host, room for 8 * (2n - 1) floats;
 // prim_idx_out: host, n ints.  Returns hipSuccess and the node count, or the failing HIP status.
-static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int leaf_max, bool use_ploc, float* bvh_out, uint64_t* n_nodes_out,
-                        int32_t* prim_idx_out, float* ms_out) {
-    Scratch sc;
+static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int leaf_max, int builder, float* bvh_out, uint64_t* n_nodes_out,
+                        int32_t* prim_idx_out, float* ms_out, ScratchPool* pool = nullptr) {
+    Scratch sc(pool);
+    MPT_LB(sc.reserve((size_t)n * 560 + ((size_t)8 << 20)));
     float4 *d_prims, *d_bvh;
     int* d_idx;
     MPT_LB(sc.alloc(&d_prims, 3 * (size_t)n));
@@ -496,7 +555,7 @@ static hipError_t build(hipStream_t stream, const float* prims, uint32_t n, int 
     auto body = [&]() -> hipError_t {
         MPT_LB(hipEventRecord(e0, stream));
         Radix R;
-        MPT_LB(build_radix(stream, sc, d_prims, n, leaf_max, use_ploc, R));
+        MPT_LB(build_radix(stream, sc, d_prims, n, leaf_max, builder, R));
         MPT_LB(emit_reference_format(stream, R, d_bvh, d_idx));
         MPT_LB(hipEventRecord(e1, stream));
         MPT_LB(hipStreamSynchronize(stream));

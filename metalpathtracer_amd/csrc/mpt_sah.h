@@ -1,0 +1,795 @@
+// mpt_sah.h — top-down binned SAH on the device, shared by the two places that build a binary tree this way: the own 4-wide
+// tree of the closest-first pipeline (mpt_devbuild.h: items = the leaves) and the binary tree under the reference-format
+// arrays (mpt_lbvh.h build_radix, builder "sah": items = the primitives).  It is the host builder's algorithm
+// (mpt_accel.h / Scene::buildBVH(BVH_BINNED_CENTROID): 16 bins over the box centres, cost = area * primitives) run level by
+// level: a WORKGROUP per node for the few long tasks at the top, a WAVE per node in the middle, and one lane per item — eight
+// nodes to a wave, whole sub-tree in one go — for the nodes of at most MPT_SAH_SMALL items, which are most of the tree.
+// Stands where the reference has Scene::buildBVHRecursive (R/Scene/Scene.h:195-317: full-sweep SAH over std::sort).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+namespace mpt_lbvh {
+// Scratch memory of a build: a bump allocator over a few large chunks (a build makes ~90 arrays; one hipMalloc each cost a
+// third of the 1 M-primitive build), freed — or handed back to the pool they came from — on every exit path.  A ScratchPool
+// (one per context) keeps the chunks between builds: a rebuild allocates nothing.
+struct ScratchPool {
+    std::vector<std::pair<void*, size_t>> chunks;
+    size_t keep_bytes = (size_t)2 << 30;   // what stays allocated between builds at most
+    ~ScratchPool() { release(); }
+    void release() {
+        for (auto& c : chunks) hipFree(c.first);
+        chunks.clear();
+    }
+};
+struct Scratch {
+    ScratchPool* pool;
+    std::vector<std::pair<void*, size_t>> mine;
+    size_t off = 0;   // in the last chunk of mine
+    explicit Scratch(ScratchPool* p = nullptr) : pool(p) {}
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch() {
+        size_t kept = 0;
+        if (pool)
+            for (auto& c : pool->chunks) kept += c.second;
+        for (auto& c : mine) {
+            if (pool && kept + c.second <= pool->keep_bytes) {
+                pool->chunks.push_back(c);
+                kept += c.second;
+            } else {
+                hipFree(c.first);
+            }
+        }
+    }
+    // a chunk of at least `bytes` becomes the current one: the pool's smallest that fits, else a new allocation
+    hipError_t chunk(size_t bytes) {
+        if (pool) {
+            int best = -1;
+            for (int i = 0; i < (int)pool->chunks.size(); ++i)
+                if (pool->chunks[i].second >= bytes && (best < 0 || pool->chunks[i].second < pool->chunks[best].second)) best = i;
+            if (best >= 0) {
+                mine.push_back(pool->chunks[best]);
+                pool->chunks.erase(pool->chunks.begin() + best);
+                off = 0;
+                return hipSuccess;
+            }
+        }
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) return e;
+        mine.emplace_back(q, bytes);
+        off = 0;
+        return hipSuccess;
+    }
+    // (call once with an estimate of everything the build will ask for: one chunk instead of several)
+    hipError_t reserve(size_t bytes) { return chunk(std::max<size_t>(bytes, (size_t)1 << 20)); }
+    template <class T>
+    hipError_t alloc(T** p, size_t count) {
+        const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+        if (mine.empty() || off + bytes > mine.back().second) {
+            *p = nullptr;
+            hipError_t e = chunk(std::max<size_t>(bytes, (size_t)64 << 20));
+            if (e != hipSuccess) return e;
+        }
+        *p = (T*)((char*)mine.back().first + off);
+        off += bytes;
+        return hipSuccess;
+    }
+};
+
+#define MPT_LB(call)                       \
+    do {                                   \
+        hipError_t e_ = (call);            \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+}  // namespace mpt_lbvh
+
+namespace mpt_sah {
+using mpt_lbvh::Scratch;
+
+// Item record, 32 bytes, moved along by every partition (the passes stream it, nothing is looked up through an index):
+//   lo = (box min, bits(id))   hi = (box max, bits(primitives in the item))
+// Node ids: an item's id (< top) is a leaf; top + k is inner node k, whose children are child[k] and whose box lo[k], hi[k]
+// (lo[k].w = bits(items below it)).  Node 0 is the root when there is more than one item.
+struct SahTask {
+    uint32_t b, e;     // items [b, e) of the current index array
+    int parent;        // inner node that waits for this sub-tree (-1: the root)
+    uint32_t side;
+};
+#ifndef MPT_SAH_BIG
+#define MPT_SAH_BIG 2048u   // tasks of at least this many items get a whole workgroup (k_sah_level_big), smaller ones a wave
+#endif
+#ifndef MPT_SAH_SAMPLE
+#define MPT_SAH_SAMPLE 256u  // a wave's task bins an evenly spaced sample of about this many of its items
+#endif
+#ifndef MPT_SAH_SMALL
+#define MPT_SAH_SMALL 8u     // tasks of at most this many items (8 or 16) are FINISHED, sub-tree and all, by as many lanes (k_sah_small)
+#endif
+struct SahState {
+    uint32_t n_next;        // tasks pushed for the next level (a wave each)
+    uint32_t n_next_big;    // ... the big ones (a workgroup each)
+    uint32_t n_next_small;  // ... and the small ones (a lane per item)
+    uint32_t n_nodes;  // inner nodes created
+    int root;          // -1: no items
+    uint32_t n_items;
+};
+__device__ __forceinline__ float half_area4(float4 lo, float4 hi) {
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ __forceinline__ bool empty4(float4 lo, float4 hi) { return !(hi.x >= lo.x && hi.y >= lo.y && hi.z >= lo.z); }
+__device__ __forceinline__ float axis_of(float4 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
+__device__ __forceinline__ int f2o(float f) {  // order-preserving float -> int
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void k_sah_init(const uint32_t* count /* device word, or null */, uint32_t count_host, SahState* st, SahTask* tasks, SahTask* big_tasks,
+                           SahTask* small_tasks) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t m = count ? *count : count_host;
+    st->n_items = m;
+    st->n_nodes = 0u;
+    st->root = -1;
+    st->n_next = 0u;
+    st->n_next_big = 0u;
+    st->n_next_small = 0u;
+    if (m >= MPT_SAH_BIG) {
+        big_tasks[0] = SahTask{0u, m, -1, 0u};
+        st->n_next_big = 1u;
+    } else if (m >= 2u && m <= MPT_SAH_SMALL) {
+        small_tasks[0] = SahTask{0u, m, -1, 0u};
+        st->n_next_small = 1u;
+    } else if (m != 0u) {
+        tasks[0] = SahTask{0u, m, -1, 0u};
+        st->n_next = 1u;
+    }
+}
+#define MPT_SAH_WAVES 4   // per workgroup
+__device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int parent, uint32_t side, int id) {
+    if (parent < 0) st->root = id;
+    else if (side == 0u) s_child[parent].x = id;
+    else s_child[parent].y = id;
+}
+// a finished split: a single item is attached at once, anything larger becomes a task of the next level
+__device__ __forceinline__ void sah_push_children(SahState* st, int2* s_child, SahTask* next, SahTask* next_big, SahTask* next_small, uint32_t b,
+                                                  uint32_t e, uint32_t nlft, uint32_t k, int one_left, int one_right) {
+    const uint32_t mid = b + nlft, nrgt = e - mid;
+    if (nlft == 1u) s_child[k].x = one_left;
+    else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = SahTask{b, mid, (int)k, 0u};
+    else if (nlft <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = SahTask{b, mid, (int)k, 0u};
+    else next[atomicAdd(&st->n_next, 1u)] = SahTask{b, mid, (int)k, 0u};
+    if (nrgt == 1u) s_child[k].y = one_right;
+    else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = SahTask{mid, e, (int)k, 1u};
+    else if (nrgt <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = SahTask{mid, e, (int)k, 1u};
+    else next[atomicAdd(&st->n_next, 1u)] = SahTask{mid, e, (int)k, 1u};
+}
+__global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi,
+                                                                  const SahTask* tasks, uint32_t n_tasks, SahTask* next, SahTask* next_big, SahTask* next_small,
+                                                                  SahState* st, int2* s_child, float4* s_lo, float4* s_hi) {
+    __shared__ int bins[MPT_SAH_WAVES][3][16][7];   // per wave: (lo xyz, hi xyz as ordered ints, primitive count) per axis and bin
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * MPT_SAH_WAVES + wv;
+    if (t >= n_tasks) return;
+    const int TOP = 2 * n - 1;
+    const SahTask task = tasks[t];
+    const uint32_t b = task.b, e = task.e, m = e - b;
+    if (m == 1u) {   // (only the root task of a one-leaf tree comes here: children of one item are attached when they are split off)
+        if (lane == 0) sah_attach(st, s_child, task.parent, task.side, __float_as_int(in_lo[b].w));
+        return;
+    }
+    if (m == 2u) {   // two items: the node, nothing to choose (a third of all tasks, at the bottom of the tree)
+        if (lane == 0) {
+            const float4 l0 = in_lo[b], h0 = in_hi[b], l1 = in_lo[b + 1u], h1 = in_hi[b + 1u];
+            const uint32_t k2 = atomicAdd(&st->n_nodes, 1u);
+            s_lo[k2] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), __int_as_float(2));
+            s_hi[k2] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
+            s_child[k2] = make_int2(__float_as_int(l0.w), __float_as_int(l1.w));
+            sah_attach(st, s_child, task.parent, task.side, TOP + (int)k2);
+        }
+        return;
+    }
+    // pass 1: the node's box and the bounds of the box centres
+    float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
+          ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = b + lane; i < e; i += 64u) {
+        const float4 l = in_lo[i], h = in_hi[i];
+        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
+        for (int a = 0; a < 3; ++a) {
+            nl[a] = fminf(nl[a], lo3[a]);
+            nh[a] = fmaxf(nh[a], hi3[a]);
+            const float c = 0.5f * (lo3[a] + hi3[a]);
+            cl[a] = fminf(cl[a], c);
+            ch[a] = fmaxf(ch[a], c);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int a = 0; a < 3; ++a) {
+            nl[a] = fminf(nl[a], __shfl_xor(nl[a], off));
+            nh[a] = fmaxf(nh[a], __shfl_xor(nh[a], off));
+            cl[a] = fminf(cl[a], __shfl_xor(cl[a], off));
+            ch[a] = fmaxf(ch[a], __shfl_xor(ch[a], off));
+        }
+    uint32_t k = 0;
+    if (lane == 0) {
+        k = atomicAdd(&st->n_nodes, 1u);
+        s_lo[k] = make_float4(nl[0], nl[1], nl[2], __int_as_float((int)m));   // (.w: items below the node)
+        s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
+        sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
+    }
+    k = (uint32_t)__shfl((int)k, 0);
+    // pass 2: bins
+    for (uint32_t q = lane; q < 3u * 16u * 7u; q += 64u) {
+        const uint32_t f = q % 7u;
+        (&bins[wv][0][0][0])[q] = f < 3u ? 0x7FFFFFFF : f < 6u ? (int)0x80000000 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float inv[3];
+    for (int a = 0; a < 3; ++a) {
+        const float ext = ch[a] - cl[a];
+        inv[a] = ext > 0.0f && isfinite(ext) ? 16.0f / ext : 0.0f;
+    }
+    // (a node of more than 256 items is binned from an evenly spaced sample of ~256 of them: the 21 LDS atomics per item are
+    //  what this pass costs, and 256 boxes choose among 45 planes as well as 100,000 do; box and partition stay exact)
+    const uint32_t step = m > MPT_SAH_SAMPLE ? m / MPT_SAH_SAMPLE : 1u;
+    for (uint32_t i = b + lane * step; i < e; i += 64u * step) {
+        const float4 l = in_lo[i], h = in_hi[i];
+        const int cnt = __float_as_int(h.w);
+        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
+        for (int a = 0; a < 3; ++a) {
+            if (inv[a] == 0.0f) continue;
+            int q = (int)((0.5f * (lo3[a] + hi3[a]) - cl[a]) * inv[a]);
+            q = q < 0 ? 0 : (q > 15 ? 15 : q);
+            int* B = bins[wv][a][q];
+            atomicMin(&B[0], f2o(l.x)); atomicMin(&B[1], f2o(l.y)); atomicMin(&B[2], f2o(l.z));
+            atomicMax(&B[3], f2o(h.x)); atomicMax(&B[4], f2o(h.y)); atomicMax(&B[5], f2o(h.z));
+            atomicAdd(&B[6], cnt);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // pass 3: lane = (axis, split after bin s): cost = area(L) * count(L) + area(R) * count(R)
+    float cost = INFINITY;
+    if (lane < 45u) {
+        const int a = (int)(lane / 15u), sp = (int)(lane % 15u);
+        if (inv[a] != 0.0f) {
+            float L[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, R[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int cL = 0, cR = 0;
+            for (int q = 0; q < 16; ++q) {
+                const int* B = bins[wv][a][q];
+                if (B[6] == 0) continue;
+                float* D = q <= sp ? L : R;
+                for (int c = 0; c < 3; ++c) {
+                    D[c] = fminf(D[c], o2f(B[c]));
+                    D[3 + c] = fmaxf(D[3 + c], o2f(B[3 + c]));
+                }
+                if (q <= sp) cL += B[6];
+                else cR += B[6];
+            }
+            if (cL != 0 && cR != 0)
+                cost = half_area4(make_float4(L[0], L[1], L[2], 0), make_float4(L[3], L[4], L[5], 0)) * (float)cL +
+                       half_area4(make_float4(R[0], R[1], R[2], 0), make_float4(R[3], R[4], R[5], 0)) * (float)cR;
+        }
+    }
+    float best = cost;
+    for (int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_xor(best, off));
+    const unsigned long long who = __ballot(cost == best && best < INFINITY);
+    const int pick = who != 0ull ? (int)__ffsll((long long)who) - 1 : -1;   // ties: the lowest (axis, split)
+    const int paxis = pick >= 0 ? pick / 15 : 0, psplit = pick >= 0 ? pick % 15 : 0;
+    // partition into the other array: left from b upwards, right from e - 1 downwards
+    uint32_t nlft = 0, nrgt = 0;
+    int one_left = 0, one_right = 0;   // (the first item that went to either side: THE item if it stays alone)
+    for (uint32_t base = b; base < e; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool valid = i < e;
+        float4 l = make_float4(0, 0, 0, 0), h = l;
+        bool left = false;
+        if (valid) {
+            l = in_lo[i];
+            h = in_hi[i];
+            if (pick >= 0) {
+                int q = (int)((0.5f * (axis_of(l, paxis) + axis_of(h, paxis)) - cl[paxis]) * inv[paxis]);
+                q = q < 0 ? 0 : (q > 15 ? 15 : q);
+                left = q <= psplit;
+            } else {
+                left = i - b < m / 2u;   // no plane separates the box centres: halves
+            }
+        }
+        const unsigned long long lm = __ballot(valid && left), rm = __ballot(valid && !left);
+        if (valid) {
+            const uint32_t dst = left ? b + nlft + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))
+                                      : e - 1u - nrgt - (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
+            out_lo[dst] = l;
+            out_hi[dst] = h;
+        }
+        if (nlft == 0u && lm != 0ull) one_left = __shfl(__float_as_int(l.w), __ffsll((long long)lm) - 1);
+        if (nrgt == 0u && rm != 0ull) one_right = __shfl(__float_as_int(l.w), __ffsll((long long)rm) - 1);
+        nlft += (uint32_t)__popcll(lm);
+        nrgt += (uint32_t)__popcll(rm);
+    }
+    if (lane == 0) sah_push_children(st, s_child, next, next_big, next_small, b, e, nlft, k, one_left, one_right);
+}
+
+// The same for the BIG tasks of a level (>= MPT_SAH_BIG items: the top ten levels of a 1 M-primitive tree, one to a few hundred
+// tasks over ALL the items).  One workgroup per task would leave the chip idle exactly where the passes are longest (the root:
+// one workgroup streaming 1 M items three times, 1.1 ms), so the two passes that touch every item — the bounds and the
+// partition — run over CHUNKS of 2048 items, a workgroup each, whatever task a chunk belongs to:
+//   k_big_prep     the tasks' first chunk numbers (prefix over ceil(items / 2048)), accumulators reset          1 workgroup
+//   k_big_bounds   node box + bounds of the box centres, a chunk each, merged by atomics                          per chunk
+//   k_big_pick     bins from an evenly spaced sample of ~4096 items, the 45 planes priced, the node made          per task
+//   k_big_count    items that go left, per chunk                                                                  per chunk
+//   k_big_scatter  the partition: left from b upwards, right from e - 1 downwards, in item order (deterministic)  per chunk
+//   k_big_push     the children: tasks of the next level, or single items attached                                per task
+#define MPT_SAH_BIG_THREADS 1024
+#define MPT_SAH_CHUNK 2048u
+#define MPT_SAH_CHUNK_THREADS 256u
+#ifndef MPT_SAH_SAMPLE_BIG
+#define MPT_SAH_SAMPLE_BIG 4096u
+#endif
+struct SahBig {
+    int bounds[12];   // node box lo / hi, centre bounds lo / hi (ordered ints)
+    uint32_t k;       // the node
+    int pick;         // axis * 15 + split, or -1: halves
+    float cl[3], inv[3];
+    int one[2];       // id of the first item on either side (THE item if it stays alone)
+};
+__device__ __forceinline__ uint32_t sah_chunks(const SahTask& t) { return (t.e - t.b + MPT_SAH_CHUNK - 1u) / MPT_SAH_CHUNK; }
+__global__ __launch_bounds__(1024) void k_big_prep(const SahTask* tasks, uint32_t n_big, SahBig* big, uint32_t* coff /* [n_big + 1] */) {
+    __shared__ uint32_t s_w[16], s_run;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) s_run = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_big; base += 1024u) {
+        const uint32_t t = base + tid;
+        const uint32_t c = t < n_big ? sah_chunks(tasks[t]) : 0u;
+        uint32_t x = c;   // inclusive prefix within the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if ((int)lane >= off) x += y;
+        }
+        if (lane == 63u) s_w[wv] = x;
+        __syncthreads();
+        uint32_t before = s_run;
+        for (uint32_t w = 0; w < wv; ++w) before += s_w[w];
+        if (t < n_big) {
+            coff[t] = before + x - c;
+            SahBig& B = big[t];
+            for (int q = 0; q < 12; ++q) B.bounds[q] = q % 6 < 3 ? 0x7FFFFFFF : (int)0x80000000;
+            B.one[0] = B.one[1] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023u) s_run = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) coff[n_big] = s_run;
+}
+// the task a chunk belongs to: the last t with coff[t] <= c
+__device__ __forceinline__ uint32_t sah_task_of_chunk(const uint32_t* coff, uint32_t n_big, uint32_t c) {
+    uint32_t lo = 0, hi = n_big;   // coff[lo] <= c < coff[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (coff[mid] <= c) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const float4* in_lo, const float4* in_hi, const SahTask* tasks, uint32_t n_big,
+                                                                      const uint32_t* coff, SahBig* big) {
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    if (c >= coff[n_big]) return;
+    const uint32_t t = sah_task_of_chunk(coff, n_big, c);
+    const SahTask task = tasks[t];
+    const uint32_t b = task.b + (c - coff[t]) * MPT_SAH_CHUNK, e = b + MPT_SAH_CHUNK < task.e ? b + MPT_SAH_CHUNK : task.e;
+    float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
+          ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = b + tid; i < e; i += MPT_SAH_CHUNK_THREADS) {
+        const float4 l = in_lo[i], h = in_hi[i];
+        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
+        for (int a = 0; a < 3; ++a) {
+            nl[a] = fminf(nl[a], lo3[a]);
+            nh[a] = fmaxf(nh[a], hi3[a]);
+            const float cc = 0.5f * (lo3[a] + hi3[a]);
+            cl[a] = fminf(cl[a], cc);
+            ch[a] = fmaxf(ch[a], cc);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int a = 0; a < 3; ++a) {
+            nl[a] = fminf(nl[a], __shfl_xor(nl[a], off));
+            nh[a] = fmaxf(nh[a], __shfl_xor(nh[a], off));
+            cl[a] = fminf(cl[a], __shfl_xor(cl[a], off));
+            ch[a] = fmaxf(ch[a], __shfl_xor(ch[a], off));
+        }
+    if (lane == 0) {
+        int* B = big[t].bounds;
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&B[a], f2o(nl[a]));
+            atomicMax(&B[3 + a], f2o(nh[a]));
+            atomicMin(&B[6 + a], f2o(cl[a]));
+            atomicMax(&B[9 + a], f2o(ch[a]));
+        }
+    }
+}
+__global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahBig* big, SahState* st,
+                                                                  int2* s_child, float4* s_lo, float4* s_hi) {
+    __shared__ int bins[3][16][7];
+    __shared__ float s_cost[48];
+    const uint32_t tid = threadIdx.x;
+    const int TOP = 2 * n - 1;
+    const SahTask task = tasks[blockIdx.x];
+    SahBig& G = big[blockIdx.x];
+    const uint32_t b = task.b, e = task.e, m = e - b;
+    for (uint32_t q = tid; q < 3u * 16u * 7u; q += MPT_SAH_BIG_THREADS) {
+        const uint32_t f = q % 7u;
+        (&bins[0][0][0])[q] = f < 3u ? 0x7FFFFFFF : f < 6u ? (int)0x80000000 : 0;
+    }
+    float cl[3], inv[3];
+    for (int a = 0; a < 3; ++a) {
+        cl[a] = o2f(G.bounds[6 + a]);
+        const float ext = o2f(G.bounds[9 + a]) - cl[a];
+        inv[a] = ext > 0.0f && isfinite(ext) ? 16.0f / ext : 0.0f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t k = atomicAdd(&st->n_nodes, 1u);
+        G.k = k;
+        s_lo[k] = make_float4(o2f(G.bounds[0]), o2f(G.bounds[1]), o2f(G.bounds[2]), __int_as_float((int)m));
+        s_hi[k] = make_float4(o2f(G.bounds[3]), o2f(G.bounds[4]), o2f(G.bounds[5]), 0.0f);
+        sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
+    }
+    const uint32_t step = m > MPT_SAH_SAMPLE_BIG ? m / MPT_SAH_SAMPLE_BIG : 1u;   // (binned from a sample of ~4096 items: see k_sah_level)
+    for (uint32_t i = b + tid * step; i < e; i += MPT_SAH_BIG_THREADS * step) {
+        const float4 l = in_lo[i], h = in_hi[i];
+        const int cnt = __float_as_int(h.w);
+        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
+        for (int a = 0; a < 3; ++a) {
+            if (inv[a] == 0.0f) continue;
+            int q = (int)((0.5f * (lo3[a] + hi3[a]) - cl[a]) * inv[a]);
+            q = q < 0 ? 0 : (q > 15 ? 15 : q);
+            int* B = bins[a][q];
+            atomicMin(&B[0], f2o(l.x)); atomicMin(&B[1], f2o(l.y)); atomicMin(&B[2], f2o(l.z));
+            atomicMax(&B[3], f2o(h.x)); atomicMax(&B[4], f2o(h.y)); atomicMax(&B[5], f2o(h.z));
+            atomicAdd(&B[6], cnt);
+        }
+    }
+    __syncthreads();
+    if (tid < 48u) {
+        float cost = INFINITY;
+        if (tid < 45u) {
+            const int a = (int)(tid / 15u), sp = (int)(tid % 15u);
+            if (inv[a] != 0.0f) {
+                float L[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, R[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int cL = 0, cR = 0;
+                for (int q = 0; q < 16; ++q) {
+                    const int* B = bins[a][q];
+                    if (B[6] == 0) continue;
+                    float* D = q <= sp ? L : R;
+                    for (int c = 0; c < 3; ++c) {
+                        D[c] = fminf(D[c], o2f(B[c]));
+                        D[3 + c] = fmaxf(D[3 + c], o2f(B[3 + c]));
+                    }
+                    if (q <= sp) cL += B[6];
+                    else cR += B[6];
+                }
+                if (cL != 0 && cR != 0)
+                    cost = half_area4(make_float4(L[0], L[1], L[2], 0), make_float4(L[3], L[4], L[5], 0)) * (float)cL +
+                           half_area4(make_float4(R[0], R[1], R[2], 0), make_float4(R[3], R[4], R[5], 0)) * (float)cR;
+            }
+        }
+        s_cost[tid] = cost;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pick = -1;
+        float best = INFINITY;
+        for (int q = 0; q < 45; ++q)
+            if (s_cost[q] < best) best = s_cost[q], pick = q;   // ties: the lowest (axis, split), as in the wave kernel
+        G.pick = pick;
+        for (int a = 0; a < 3; ++a) G.cl[a] = cl[a], G.inv[a] = inv[a];
+    }
+}
+// which side item i of the task goes to
+__device__ __forceinline__ bool sah_big_left(const SahBig& G, const SahTask& task, uint32_t i, float4 l, float4 h) {
+    if (G.pick < 0) return i - task.b < (task.e - task.b) / 2u;   // no plane separates the box centres: halves
+    const int a = G.pick / 15, sp = G.pick % 15;
+    int q = (int)((0.5f * (axis_of(l, a) + axis_of(h, a)) - G.cl[a]) * G.inv[a]);
+    q = q < 0 ? 0 : (q > 15 ? 15 : q);
+    return q <= sp;
+}
+__global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float4* in_lo, const float4* in_hi, const SahTask* tasks, uint32_t n_big,
+                                                                     const uint32_t* coff, const SahBig* big, uint32_t* chunk_left) {
+    __shared__ uint32_t s_w[MPT_SAH_CHUNK_THREADS / 64u];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (c >= coff[n_big]) return;
+    const uint32_t t = sah_task_of_chunk(coff, n_big, c);
+    const SahTask task = tasks[t];
+    const SahBig G = big[t];
+    const uint32_t b = task.b + (c - coff[t]) * MPT_SAH_CHUNK, e = b + MPT_SAH_CHUNK < task.e ? b + MPT_SAH_CHUNK : task.e;
+    uint32_t cnt = 0;
+    for (uint32_t i = b + tid; i < e; i += MPT_SAH_CHUNK_THREADS) cnt += sah_big_left(G, task, i, in_lo[i], in_hi[i]) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) s_w[wv] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t sum = 0;
+        for (uint32_t w = 0; w < MPT_SAH_CHUNK_THREADS / 64u; ++w) sum += s_w[w];
+        chunk_left[c] = sum;
+    }
+}
+__global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
+                                                                       uint32_t n_big, const uint32_t* coff, SahBig* big, const uint32_t* chunk_left) {
+    constexpr uint32_t NW = MPT_SAH_CHUNK_THREADS / 64u;
+    __shared__ uint32_t s_wl[NW], s_wr[NW], s_before[NW];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (c >= coff[n_big]) return;
+    const uint32_t t = sah_task_of_chunk(coff, n_big, c);
+    const SahTask task = tasks[t];
+    const SahBig G = big[t];
+    const uint32_t j = c - coff[t];
+    const uint32_t b = task.b + j * MPT_SAH_CHUNK, e = b + MPT_SAH_CHUNK < task.e ? b + MPT_SAH_CHUNK : task.e;
+    // items that went left in the task's chunks before this one
+    uint32_t lb = 0;
+    for (uint32_t q = tid; q < j; q += MPT_SAH_CHUNK_THREADS) lb += chunk_left[coff[t] + q];
+    for (int off = 32; off > 0; off >>= 1) lb += __shfl_xor(lb, off);
+    if (lane == 0) s_before[wv] = lb;
+    __syncthreads();
+    uint32_t nlft = 0;
+    for (uint32_t w = 0; w < NW; ++w) nlft += s_before[w];
+    uint32_t nrgt = j * MPT_SAH_CHUNK - nlft;
+    __syncthreads();
+    for (uint32_t base = b; base < e; base += MPT_SAH_CHUNK_THREADS) {
+        const uint32_t i = base + tid;
+        const bool valid = i < e;
+        float4 l = make_float4(0, 0, 0, 0), h = l;
+        bool left = false;
+        if (valid) {
+            l = in_lo[i];
+            h = in_hi[i];
+            left = sah_big_left(G, task, i, l, h);
+        }
+        const unsigned long long lm = __ballot(valid && left), rm = __ballot(valid && !left);
+        if (lane == 0) {
+            s_wl[wv] = (uint32_t)__popcll(lm);
+            s_wr[wv] = (uint32_t)__popcll(rm);
+        }
+        __syncthreads();
+        uint32_t pl = 0, pr = 0, tl = 0, tr = 0;
+        for (uint32_t w = 0; w < NW; ++w) {
+            if (w < wv) pl += s_wl[w], pr += s_wr[w];
+            tl += s_wl[w];
+            tr += s_wr[w];
+        }
+        if (valid) {
+            const uint32_t dst = left ? task.b + nlft + pl + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))
+                                      : task.e - 1u - nrgt - pr - (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
+            out_lo[dst] = l;
+            out_hi[dst] = h;
+            if (dst == task.b && left) big[t].one[0] = __float_as_int(l.w);
+            if (dst == task.e - 1u && !left) big[t].one[1] = __float_as_int(l.w);
+        }
+        nlft += tl;
+        nrgt += tr;
+        __syncthreads();
+    }
+}
+__global__ void k_big_push(const SahTask* tasks, uint32_t n_big, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
+                           SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_big) return;
+    uint32_t nlft = 0;
+    for (uint32_t c = coff[t]; c < coff[t + 1u]; ++c) nlft += chunk_left[c];
+    sah_push_children(st, s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1]);
+}
+
+// ... and for a SMALL task (<= MPT_SAH_SMALL items: the last three or four levels, which hold most of the tree's nodes and took
+// 70 % of the builder's time at a wave per node): one lane per item, 8 tasks per wave, and the group finishes the whole
+// sub-tree — every round splits ALL the ranges the group holds at once (segmented reductions over the group's lanes by
+// shuffles, the partition by ds_permute), so no task of the bottom levels is ever queued.  Same algorithm and same choices as
+// k_sah_level (16 bins over the box centres, cost = area * primitives, ties to the lowest (axis, split)); a lane prices the
+// three planes behind its own item's bins, which are all the planes that separate anything.
+__global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, uint32_t n_tasks, SahState* st,
+                                                   int2* s_child, float4* s_lo, float4* s_hi) {
+    constexpr uint32_t G = MPT_SAH_SMALL;
+    static_assert(G == 8u || G == 16u, "MPT_SAH_SMALL: 8 or 16");
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / G, lane = threadIdx.x & 63u, gl = lane & (G - 1u), gbase = lane & ~(G - 1u);
+    const int TOP = 2 * n - 1;
+    SahTask task = SahTask{0u, 0u, -1, 0u};
+    if (t < n_tasks) task = tasks[t];
+    bool live = gl < task.e - task.b;
+    float4 l = make_float4(0, 0, 0, 0), h = l;
+    if (live) {
+        l = in_lo[task.b + gl];
+        h = in_hi[task.b + gl];
+    }
+    uint32_t rb = 0u, re = task.e - task.b;   // this lane's range, in lanes of the group
+    int parent = task.parent;
+    uint32_t side = task.side;
+    for (uint32_t round = 0; round < G; ++round) {
+        if (__ballot(live) == 0ull) break;
+        // the range's box, the bounds of its box centres
+        const float c3[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+        float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
+              ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < G; ++i) {
+            const int src = (int)(gbase + i);
+            const bool same = __shfl((int)live, src) != 0 && (uint32_t)__shfl((int)rb, src) == rb;
+            const float lo3[3] = {__shfl(l.x, src), __shfl(l.y, src), __shfl(l.z, src)}, hi3[3] = {__shfl(h.x, src), __shfl(h.y, src), __shfl(h.z, src)};
+            if (same)
+                for (int a = 0; a < 3; ++a) {
+                    nl[a] = fminf(nl[a], lo3[a]);
+                    nh[a] = fmaxf(nh[a], hi3[a]);
+                    const float c = 0.5f * (lo3[a] + hi3[a]);
+                    cl[a] = fminf(cl[a], c);
+                    ch[a] = fmaxf(ch[a], c);
+                }
+        }
+        const uint32_t m = re - rb;
+        uint32_t k = 0;
+        if (live && gl == rb) {
+            k = atomicAdd(&st->n_nodes, 1u);
+            s_lo[k] = make_float4(nl[0], nl[1], nl[2], __int_as_float((int)m));
+            s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
+            sah_attach(st, s_child, parent, side, TOP + (int)k);
+        }
+        k = (uint32_t)__shfl((int)k, (int)(gbase + rb));
+        // bins of this lane's item; the plane behind each of them, priced over the range
+        float inv[3];
+        int q3[3];
+        for (int a = 0; a < 3; ++a) {
+            const float ext = ch[a] - cl[a];
+            inv[a] = ext > 0.0f && isfinite(ext) ? 16.0f / ext : 0.0f;
+            int q = (int)((c3[a] - cl[a]) * inv[a]);
+            q3[a] = q < 0 ? 0 : (q > 15 ? 15 : q);
+        }
+        const int qpack = q3[0] | (q3[1] << 4) | (q3[2] << 8);
+        float L[3][6], R[3][6];
+        int cL[3] = {0, 0, 0}, cR[3] = {0, 0, 0};
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 6; ++c) L[a][c] = R[a][c] = c < 3 ? INFINITY : -INFINITY;
+        for (uint32_t i = 0; i < G; ++i) {
+            const int src = (int)(gbase + i);
+            const bool same = __shfl((int)live, src) != 0 && (uint32_t)__shfl((int)rb, src) == rb;
+            const float b6[6] = {__shfl(l.x, src), __shfl(l.y, src), __shfl(l.z, src), __shfl(h.x, src), __shfl(h.y, src), __shfl(h.z, src)};
+            const int cnt = __shfl(__float_as_int(h.w), src), qo = __shfl(qpack, src);
+            if (same)
+                for (int a = 0; a < 3; ++a) {
+                    const bool left = ((qo >> (4 * a)) & 15) <= q3[a];
+                    for (int c = 0; c < 3; ++c) {
+                        if (left) L[a][c] = fminf(L[a][c], b6[c]), L[a][3 + c] = fmaxf(L[a][3 + c], b6[3 + c]);
+                        else R[a][c] = fminf(R[a][c], b6[c]), R[a][3 + c] = fmaxf(R[a][3 + c], b6[3 + c]);
+                    }
+                    if (left) cL[a] += cnt;
+                    else cR[a] += cnt;
+                }
+        }
+        float cost = INFINITY;
+        int cand = 0x7FFFFFFF;   // axis * 15 + split
+        for (int a = 0; a < 3; ++a) {
+            if (!live || inv[a] == 0.0f || cL[a] == 0 || cR[a] == 0) continue;
+            const float c = half_area4(make_float4(L[a][0], L[a][1], L[a][2], 0), make_float4(L[a][3], L[a][4], L[a][5], 0)) * (float)cL[a] +
+                            half_area4(make_float4(R[a][0], R[a][1], R[a][2], 0), make_float4(R[a][3], R[a][4], R[a][5], 0)) * (float)cR[a];
+            const int id = a * 15 + q3[a];
+            if (c < cost || (c == cost && id < cand)) cost = c, cand = id;
+        }
+        float best = INFINITY;
+        int pick = 0x7FFFFFFF;
+        for (uint32_t i = 0; i < G; ++i) {
+            const int src = (int)(gbase + i);
+            const bool same = __shfl((int)live, src) != 0 && (uint32_t)__shfl((int)rb, src) == rb;
+            const float c = __shfl(cost, src);
+            const int id = __shfl(cand, src);
+            if (same && (c < best || (c == best && id < pick))) best = c, pick = id;
+        }
+        bool left;
+        if (best < INFINITY) left = q3[pick / 15] <= pick % 15;
+        else left = gl - rb < m / 2u;   // no plane separates the box centres: halves
+        if (m == 2u) left = gl == rb;   // (two items: nothing to choose)
+        // the partition, stable on both sides
+        const unsigned long long seg = (re - rb >= 64u ? ~0ull : ((1ull << (re - rb)) - 1ull)) << (gbase + rb);
+        const unsigned long long lm = __ballot(live && left) & seg, rm = __ballot(live && !left) & seg, below = (1ull << lane) - 1ull;
+        const uint32_t nlft = (uint32_t)__popcll(lm);
+        uint32_t dst = gl;
+        if (live) dst = left ? rb + (uint32_t)__popcll(lm & below) : rb + nlft + (uint32_t)__popcll(rm & below);
+        const int to = (int)((gbase + dst) * 4u);
+        l.x = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(l.x)));
+        l.y = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(l.y)));
+        l.z = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(l.z)));
+        l.w = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(l.w)));
+        h.x = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(h.x)));
+        h.y = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(h.y)));
+        h.z = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(h.z)));
+        h.w = __int_as_float(__builtin_amdgcn_ds_permute(to, __float_as_int(h.w)));
+        // (a lane stays in its old range, so the range's nlft and k are still the ones it knows)
+        if (live) {
+            parent = (int)k;
+            if (gl < rb + nlft) re = rb + nlft, side = 0u;
+            else rb = rb + nlft, side = 1u;
+            if (re - rb == 1u) {   // alone: attached at once
+                if (side == 0u) s_child[k].x = __float_as_int(l.w);
+                else s_child[k].y = __float_as_int(l.w);
+                live = false;
+            }
+        }
+    }
+}
+
+struct SahTree {
+    int2* child = nullptr;
+    float4 *lo = nullptr, *hi = nullptr;
+    SahState* st = nullptr;   // on the device: root, n_nodes
+};
+// it_lo / it_hi: the items (device, consumed: the partitions ping-pong between them and two scratch arrays).  The item count
+// is *d_count if d_count is not null (a device word), else count_host; max_items bounds it.  pin: >= 64 bytes of pinned
+// host memory for the per-level read-back.  The stream is synchronised once per level (about 12 + log2(items / 8) levels).
+static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int top, const uint32_t* d_count, uint32_t count_host, uint32_t max_items,
+                          float4* it_lo_a, float4* it_hi_a, SahTree& T) {
+    float4 *it_lo_b, *it_hi_b;
+    SahTask *tasks_a, *tasks_b, *big_a, *big_b, *small_a, *small_b;
+    MPT_LB(sc.alloc(&T.st, 1));
+    MPT_LB(sc.alloc(&it_lo_b, max_items));
+    MPT_LB(sc.alloc(&it_hi_b, max_items));
+    MPT_LB(sc.alloc(&tasks_a, max_items + 2));
+    MPT_LB(sc.alloc(&tasks_b, max_items + 2));
+    MPT_LB(sc.alloc(&big_a, max_items / MPT_SAH_BIG + 2));
+    MPT_LB(sc.alloc(&big_b, max_items / MPT_SAH_BIG + 2));
+    MPT_LB(sc.alloc(&small_a, max_items / 2 + 2));
+    MPT_LB(sc.alloc(&small_b, max_items / 2 + 2));
+    const uint32_t max_big = max_items / MPT_SAH_BIG + 2;
+    SahBig* bigs;
+    uint32_t *coff, *chunk_left;
+    MPT_LB(sc.alloc(&bigs, max_big));
+    MPT_LB(sc.alloc(&coff, max_big + 1));
+    MPT_LB(sc.alloc(&chunk_left, max_items / MPT_SAH_CHUNK + max_big + 1));
+    MPT_LB(sc.alloc(&T.child, max_items));
+    MPT_LB(sc.alloc(&T.lo, max_items));
+    MPT_LB(sc.alloc(&T.hi, max_items));
+    // (k_sah_* take n with top = 2n - 1)
+    const int n = (top + 1) / 2;
+    hipLaunchKernelGGL(k_sah_init, dim3(1), dim3(64), 0, stream, d_count, count_host, T.st, tasks_a, big_a, small_a);
+    SahState& h = *(SahState*)pin;
+    MPT_LB(hipMemcpyAsync(&h, T.st, sizeof h, hipMemcpyDeviceToHost, stream));
+    MPT_LB(hipStreamSynchronize(stream));
+    uint32_t n_tasks = h.n_next, n_big = h.n_next_big, n_small = h.n_next_small;
+    for (int level = 0; level < 4096 && (n_tasks | n_big | n_small) != 0u; ++level) {
+        MPT_LB(hipMemsetAsync(&T.st->n_next, 0, 12, stream));   // n_next, n_next_big, n_next_small
+        if (n_big) {
+            const uint32_t chunks = max_items / MPT_SAH_CHUNK + n_big;   // >= sum of ceil(items / chunk) over the level's big tasks
+            hipLaunchKernelGGL(k_big_prep, dim3(1), dim3(1024), 0, stream, (const SahTask*)big_a, n_big, bigs, coff);
+            hipLaunchKernelGGL(k_big_bounds, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
+                               n_big, (const uint32_t*)coff, bigs);
+            hipLaunchKernelGGL(k_big_pick, dim3(n_big), dim3(MPT_SAH_BIG_THREADS), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a, bigs,
+                               T.st, T.child, T.lo, T.hi);
+            hipLaunchKernelGGL(k_big_count, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
+                               n_big, (const uint32_t*)coff, (const SahBig*)bigs, chunk_left);
+            hipLaunchKernelGGL(k_big_scatter, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b, it_hi_b,
+                               (const SahTask*)big_a, n_big, (const uint32_t*)coff, bigs, (const uint32_t*)chunk_left);
+            hipLaunchKernelGGL(k_big_push, dim3((n_big + 255u) / 256u), dim3(256), 0, stream, (const SahTask*)big_a, n_big, (const uint32_t*)coff, (const SahBig*)bigs,
+                               (const uint32_t*)chunk_left, tasks_b, big_b, small_b, T.st, T.child);
+        }
+        if (n_tasks)
+            hipLaunchKernelGGL(k_sah_level, dim3((n_tasks + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES), dim3(64 * MPT_SAH_WAVES), 0, stream, n, (const float4*)it_lo_a,
+                               (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, n_tasks, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi);
+        if (n_small)
+            hipLaunchKernelGGL(k_sah_small, dim3((uint32_t)(((size_t)n_small * MPT_SAH_SMALL + 255) / 256)), dim3(256), 0, stream, n, (const float4*)it_lo_a,
+                               (const float4*)it_hi_a, (const SahTask*)small_a, n_small, T.st, T.child, T.lo, T.hi);
+        MPT_LB(hipMemcpyAsync(&h, T.st, sizeof h, hipMemcpyDeviceToHost, stream));
+        MPT_LB(hipStreamSynchronize(stream));
+        n_tasks = h.n_next;
+        n_big = h.n_next_big;
+        n_small = h.n_next_small;
+        std::swap(tasks_a, tasks_b);
+        std::swap(big_a, big_b);
+        std::swap(small_a, small_b);
+        std::swap(it_lo_a, it_lo_b);
+        std::swap(it_hi_a, it_hi_b);
+    }
+    if ((n_tasks | n_big | n_small) != 0u) return hipErrorUnknown;
+    return hipGetLastError();
+}
+}  // namespace mpt_sah

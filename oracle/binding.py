@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libmpt_oracle.so")
 
 RNG_LITERAL, RNG_PHILOX = 0, 1
-BSDF_LAMBERT, BSDF_SCATTER = 0, 1
+BSDF_LAMBERT, BSDF_SCATTER, BSDF_SCATTER_ALL = 0, 1, 2
 
 COUNTER_NAMES = (
     "rays", "node_pops", "aabb_pass", "prim_tests", "sphere_tests", "tri_tests",

@@ -998,7 +998,7 @@ static Hit first_hit_bvh(const Ray& r, const float* bvh, const float* prims, con
 }
 
 enum { RNG_LITERAL = 0, RNG_PHILOX = 1 };
-enum { BSDF_LAMBERT = 0, BSDF_SCATTER = 1 };
+enum { BSDF_LAMBERT = 0, BSDF_SCATTER = 1, BSDF_SCATTER_ALL = 2 };
 
 struct PathRng {
     int mode;
@@ -1024,6 +1024,24 @@ static inline V3 random_unit_vector(const PathRng& g, uint32_t bounce, float* u_
     float rr = std::sqrt(1.0f - z * z);
     *u_extra = u01(o[2]);
     return v3(rr * c, rr * s, z);
+}
+
+// Random.h:18-30 — a point of the cube [-1,1]^3 (the seed is by value: the caller's stream does not move; literal mode
+// advances a copy three times as the reference does, philox takes words 0, 1, 2 of the bounce's block: word 2 is also
+// the Fresnel number, which only a dielectric bounce uses)
+static inline V3 random_float3(const PathRng& g, uint32_t bounce) {
+    if (g.mode == RNG_LITERAL) {
+        uint32_t s = g.seed;
+        const float x = pcg_float(s) * 2.0f - 1.0f;
+        s = pcg_hash(s);
+        const float y = pcg_float(s) * 2.0f - 1.0f;
+        s = pcg_hash(s);
+        const float z = pcg_float(s) * 2.0f - 1.0f;
+        return v3(x, y, z);
+    }
+    uint32_t o[4];
+    philox4x32_10(g.pixel, g.sample, bounce, 0u, g.key0, g.key1, o);
+    return v3(u01(o[0]) * 2.0f - 1.0f, u01(o[1]) * 2.0f - 1.0f, u01(o[2]) * 2.0f - 1.0f);
 }
 
 static inline V3 reflect(V3 i, V3 n) { return i - 2.0f * dot(n, i) * n; }
@@ -1093,7 +1111,9 @@ static void ray_color(Ray r, const float* bvh, const float* prims, const float* 
         float u_extra;
         V3 ruv = random_unit_vector(g, (uint32_t)depth, &u_extra);
         V3 newDir;
-        if (bsdf == BSDF_LAMBERT || materialType == 0.0f) {
+        if (bsdf == BSDF_SCATTER_ALL && materialType == 0.0f) {
+            newDir = normalize(hit.normal + normalize(random_float3(g, (uint32_t)depth)));  // Scatter.h:24-27,42
+        } else if (bsdf == BSDF_LAMBERT || materialType == 0.0f) {
             newDir = normalize(hit.normal + ruv);  // PathTracing.h:252-254
         } else if (materialType < 0.0f) {          // Scatter.h:28-31
             newDir = normalize(reflect(r.d, hit.normal));
@@ -1103,7 +1123,7 @@ static void ray_color(Ray r, const float* bvh, const float* prims, const float* 
                                                                 : refract(r.d, hit.normal, ri);
             newDir = normalize(newDir);
         }
-        if (bsdf == BSDF_SCATTER && materialType > 0.0f && dot(newDir, hit.normal) < 0.0f)
+        if (bsdf != BSDF_LAMBERT && materialType > 0.0f && dot(newDir, hit.normal) < 0.0f)
             r.o = hit.point - 0.0001f * hit.normal;  // transmitted ray starts on the far side (own spec)
         else
             r.o = hit.point + 0.0001f * hit.normal;  // PathTracing.h:253
@@ -1138,7 +1158,7 @@ static_assert(sizeof(Uniforms) == 144, "UniformsData must be 144 bytes");
 
 struct RenderParams {
     int32_t rng_mode;       // RNG_LITERAL / RNG_PHILOX
-    int32_t bsdf_mode;      // BSDF_LAMBERT / BSDF_SCATTER
+    int32_t bsdf_mode;      // BSDF_LAMBERT / BSDF_SCATTER / BSDF_SCATTER_ALL
     int32_t max_depth;      // reference: 32 (PathTracing.h:216)
     int32_t accumulate;     // 0: reference frame protocol (running mean, Fragment.metal:62-69); 1: sum of clamped samples
     uint32_t sample_begin;  // philox: first sample index; literal: ignored

@@ -28,6 +28,8 @@ CASES = [
     ("scene_philox_4spp_d32", "scene.xml", 64, 36, None, dict(rng_mode=ob.RNG_PHILOX, accumulate=1, max_depth=32, sample_count=4, seed=(7, 3)), dict()),
     ("cornell_philox_16spp", "cornell.xml", 64, 64, CORNELL_CAM, dict(rng_mode=ob.RNG_PHILOX, accumulate=1, max_depth=32, sample_count=16, seed=(1, 0)), dict()),
     ("glass_scatter_8spp", "glass.xml", 80, 45, None, dict(rng_mode=ob.RNG_PHILOX, bsdf_mode=ob.BSDF_SCATTER, accumulate=1, max_depth=16, sample_count=8, seed=(1, 0)), dict()),
+    ("glass_scatter_all_8spp", "glass.xml", 80, 45, None, dict(rng_mode=ob.RNG_PHILOX, bsdf_mode=ob.BSDF_SCATTER_ALL, accumulate=1, max_depth=16, sample_count=8, seed=(1, 0)), dict()),
+    ("glass_scatter_all_literal_f1", "glass.xml", 80, 45, None, dict(rng_mode=ob.RNG_LITERAL, bsdf_mode=ob.BSDF_SCATTER_ALL, accumulate=0, max_depth=16), dict(random_seed="host", frame_count=1)),
     ("bunny20_philox_2spp", "bunny20.xml", 64, 36, None, dict(rng_mode=ob.RNG_PHILOX, accumulate=1, max_depth=8, sample_count=2, seed=(1, 0)), dict()),
 ]
 

@@ -22,7 +22,7 @@ for case in range(n_cases):
     if name == "bunny20.xml": W, H = min(W, 96), min(H, 64)
     spp = int(rng.integers(1, 10)); sb = int(rng.integers(0, 5000)); depth = int(rng.choice([1, 2, 3, 8, 16, 32]))
     seed = (int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32)))
-    bsdf = 1 if name == "glass.xml" or rng.random() < 0.2 else 0
+    bsdf = int(rng.choice([1, 1, 2])) if name == "glass.xml" or rng.random() < 0.2 else 0
     pipe = int(rng.choice([3, 3, 3, 3, 2, 2, 0, 1])); shards = int(rng.choice([1, 1, 2, 3, 5]))
     cam = CORNELL_CAM if name == "cornell.xml" else None
     ctx.upload_scene(*buf); ctx.resize(W, H)

@@ -75,16 +75,19 @@ def test_gpu_built_tree_is_well_formed_and_renders_the_oracle_image(gpu_ctx, nam
         assert gpu_ctx.stats()["rays"] == ct["rays"]
 
 
-def test_gpu_build_small_inputs_and_determinism(gpu_ctx):
-    """1, 2, 9 primitives (a single leaf; the smallest trees), duplicates (equal Morton codes), and the same arrays twice."""
+@pytest.mark.parametrize("builder", ["sah", "ploc", "lbvh"])
+def test_gpu_build_small_inputs_and_determinism(gpu_ctx, builder, monkeypatch):
+    """1, 2, 3, 9 primitives (a single leaf; the smallest trees), duplicates (equal Morton codes, no separating plane), and the
+    same arrays twice: the top-down builder numbers its nodes by atomics and must still write the same arrays every time."""
+    monkeypatch.setenv("MPT_GPU_BUILD", builder)
     rng = np.random.default_rng(3)
-    for n in (1, 2, 8, 9, 100):
+    for n in (1, 2, 3, 8, 9, 17, 100, 3000):
         prims = np.zeros((n, 12), np.float32)
         prims[:, 3] = 1.0
         v0 = rng.uniform(-5, 5, (n, 3))
         prims[:, 0:3], prims[:, 4:7], prims[:, 8:11] = v0, v0 + rng.uniform(0, 1, (n, 3)), v0 + rng.uniform(0, 1, (n, 3))
-        if n == 100:
-            prims[50:] = prims[:50]                                 # exact duplicates: ties in the sort keys
+        if n >= 100:
+            prims[n // 2:] = prims[:n // 2]                         # exact duplicates: ties in the sort keys
             prims[0, 3], prims[0, 4] = 0.0, 2.5                     # and one sphere
         bvh, idx, ms = gpu_ctx.build_bvh(prims)
         _check_tree(bvh, idx, prims)
@@ -94,12 +97,15 @@ def test_gpu_build_small_inputs_and_determinism(gpu_ctx):
         assert (n <= 2) == (bvh.shape[0] == 1)                       # leaves hold <= 2 primitives by default
 
 
+@pytest.mark.parametrize("builder", ["sah", "ploc", "lbvh"])
 @pytest.mark.parametrize("name,bsdf", [("scene.xml", 0), ("glass.xml", 1), ("bunny20.xml", 0), ("cornell.xml", 0)])
-def test_build_and_upload_renders_the_oracle_image_of_its_own_tree(gpu_ctx, name, bsdf):
-    """mpt_build_and_upload: build -> render without the host.  The tree it built comes back in the reference's format
+def test_build_and_upload_renders_the_oracle_image_of_its_own_tree(gpu_ctx, name, bsdf, builder, monkeypatch):
+    """mpt_build_and_upload: build -> render without the host, with each of the three binary-tree builders (top-down binned
+    SAH, the default; PLOC clustering; the plain Karras tree).  The tree it built comes back in the reference's format
     (mpt_download_bvh); it must be well formed, and the oracle must render from it exactly what both HIP pipelines render
     from the device-resident structures (threaded tree, own 4-wide tree, always list, materials: all derived on the device)."""
     from metalpathtracer_amd import capi, host
+    monkeypatch.setenv("MPT_GPU_BUILD", builder)
     sc = host.Scene()
     st, log = host.SceneLoader.LoadSceneFromXML(scene_path(name), sc)
     assert st == 0, log

@@ -26,6 +26,7 @@ def _same(a, b):
     ("scene.xml", 101, 67, None, 32, 4, 0),       # ragged size: partial 8x8 tiles on both edges
     ("cornell.xml", 96, 96, CORNELL_CAM, 32, 8, 0),
     ("glass.xml", 128, 72, None, 16, 8, 1),
+    ("glass.xml", 128, 72, None, 16, 8, 2),
     ("bunny20.xml", 96, 54, None, 8, 2, 0),
 ])
 def test_ordered_image_bit_exact(gpu_ctx, name, W, H, cam, depth, spp, bsdf, count_work):

@@ -98,6 +98,7 @@ def test_closest_hit_matches_oracle_bitwise(gpu_ctx):
     ("scene.xml", 101, 67, None, 32, 4, 0),       # ragged size: partial 8x8 tiles on both edges
     ("cornell.xml", 96, 96, CORNELL_CAM, 32, 8, 0),
     ("glass.xml", 128, 72, None, 16, 8, 1),
+    ("glass.xml", 128, 72, None, 16, 8, 2),       # Scatter.h for every material, its own Lambert branch included
     ("bunny20.xml", 96, 54, None, 8, 2, 0),
 ])
 def test_philox_image_bit_exact(gpu_ctx, name, W, H, cam, depth, spp, bsdf, pipeline):
@@ -536,6 +537,7 @@ def test_async_renders_overlap_and_match_the_serial_result(gpu_ctx):
     ("scene.xml", 160, 90, None, 8, 8, 0),
     ("cornell.xml", 96, 96, CORNELL_CAM, 32, 8, 0),
     ("glass.xml", 128, 72, None, 16, 8, 1),
+    ("glass.xml", 128, 72, None, 16, 8, 2),
     ("bunny20.xml", 96, 54, None, 8, 2, 0),
 ])
 def test_production_kernel_variant_bit_exact(gpu_ctx, name, W, H, cam, depth, spp, bsdf):

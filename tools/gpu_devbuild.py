@@ -44,12 +44,12 @@ def scene(name, xml, bsdf, depth):
     print("%s: %d primitives" % (name, sc.getPrimitiveCount()))
     ctx = capi.Context(0)
     # (images of different trees are not compared: the few rays whose answer depends on the visit order see another order)
-    for mode, tag in ((host.BVH_BINNED_CENTROID, "host binned SAH + mpt_upload_scene"), (host.BVH_GPU_LBVH, "mpt_build_bvh (PLOC) + mpt_upload_scene")):
+    for mode, tag in ((host.BVH_BINNED_CENTROID, "host binned SAH + mpt_upload_scene"), (host.BVH_GPU_LBVH, "mpt_build_bvh (SAH) + mpt_upload_scene")):
         t0 = time.perf_counter(); sc.buildBVH(mode); t1 = time.perf_counter(); ctx.upload_scene(*sc.buffers()); t2 = time.perf_counter()
         print("  %-46s build %.1f ms + buffers/upload %.1f ms" % (tag, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
         render(ctx, sc, bsdf, depth, tag)
     prims, mats = sc.packed_primitives()
-    for env, tag in (("lbvh", "mpt_build_and_upload (Karras tree)"), ("ploc", "mpt_build_and_upload (PLOC)")):
+    for env, tag in (("lbvh", "mpt_build_and_upload (Karras tree)"), ("ploc", "mpt_build_and_upload (PLOC)"), ("sah", "mpt_build_and_upload (SAH, the default)")):
         os.environ["MPT_GPU_BUILD"] = env
         ctx.build_and_upload(prims, mats)
         best, ms = 1e9, 0
