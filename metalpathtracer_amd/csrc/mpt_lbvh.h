@@ -49,6 +49,7 @@ __global__ void k_boxes(const float4* prims, uint32_t n, float4* blo, float4* bh
         bhi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
         for (int a = 0; a < 3; ++a) c[a] = 0.5f * lo[a] + 0.5f * hi[a];
     }
+    if (!cb) return;   // (the top-down builder has no use for the bounds of the centroids: 94 k atomics on six words, 0.9 ms at 1 M)
     // wave reduction, then one atomic per wave and component
     for (int a = 0; a < 3; ++a) {
         float mn = valid && isfinite(c[a]) ? c[a] : INFINITY, mx = valid && isfinite(c[a]) ? c[a] : -INFINITY;
@@ -430,7 +431,7 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
     MPT_LB(hipMemcpyAsync(R.cb, init, sizeof init, hipMemcpyHostToDevice, stream));
     MPT_LB(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
     const uint32_t B = 256, gn = (n + B - 1) / B, gnn = (uint32_t)((nn + B - 1) / B);
-    hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, R.blo, R.bhi, R.cb);
+    hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, R.blo, R.bhi, n > 2 && builder == BUILDER_SAH ? (int*)nullptr : R.cb);
     if (n > 2 && builder == BUILDER_SAH) {
         // top-down binned SAH over the primitives (mpt_sah.h), then renumbered like the clustering's tree
         float4 *it_lo, *it_hi, *nlo0, *nhi0;

@@ -100,6 +100,9 @@ struct SahTask {
     uint32_t b, e;     // items [b, e) of the current index array
     int parent;        // inner node that waits for this sub-tree (-1: the root)
     uint32_t side;
+    uint32_t node;     // the inner node this task makes.  A sub-tree of m items has m - 1 inner nodes, numbered in pre-order from
+                       // here: the left child (nlft items) is node + 1, the right one node + nlft — no counter to contend for,
+                       // and the same tree gets the same numbers on every run
 };
 #ifndef MPT_SAH_BIG
 #define MPT_SAH_BIG 2048u   // tasks of at least this many items get a whole workgroup (k_sah_level_big), smaller ones a wave
@@ -135,66 +138,59 @@ __global__ void k_sah_init(const uint32_t* count /* device word, or null */, uin
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t m = count ? *count : count_host;
     st->n_items = m;
-    st->n_nodes = 0u;
+    st->n_nodes = m != 0u ? m - 1u : 0u;
     st->root = -1;
     st->n_next = 0u;
     st->n_next_big = 0u;
     st->n_next_small = 0u;
     if (m >= MPT_SAH_BIG) {
-        big_tasks[0] = SahTask{0u, m, -1, 0u};
+        big_tasks[0] = SahTask{0u, m, -1, 0u, 0u};
         st->n_next_big = 1u;
     } else if (m >= 2u && m <= MPT_SAH_SMALL) {
-        small_tasks[0] = SahTask{0u, m, -1, 0u};
+        small_tasks[0] = SahTask{0u, m, -1, 0u, 0u};
         st->n_next_small = 1u;
     } else if (m != 0u) {
-        tasks[0] = SahTask{0u, m, -1, 0u};
+        tasks[0] = SahTask{0u, m, -1, 0u, 0u};
         st->n_next = 1u;
     }
 }
-#define MPT_SAH_WAVES 4   // per workgroup
+#define MPT_SAH_WAVES 16   // tasks (waves) per workgroup
 __device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int parent, uint32_t side, int id) {
     if (parent < 0) st->root = id;
     else if (side == 0u) s_child[parent].x = id;
     else s_child[parent].y = id;
 }
-// a finished split: a single item is attached at once, anything larger becomes a task of the next level
+// a finished split: a single item is attached at once, anything larger becomes a task of the next level.  (Called by SEVERAL
+// lanes of a wave at once where it matters: the counters are uniform addresses, so the compiler turns each atomicAdd into one
+// atomic per wave — 150 k tasks a level each bumping the same three words one by one was 70 % of the builder's time.)
 __device__ __forceinline__ void sah_push_children(SahState* st, int2* s_child, SahTask* next, SahTask* next_big, SahTask* next_small, uint32_t b,
                                                   uint32_t e, uint32_t nlft, uint32_t k, int one_left, int one_right) {
     const uint32_t mid = b + nlft, nrgt = e - mid;
+    const SahTask L = SahTask{b, mid, (int)k, 0u, k + 1u}, R = SahTask{mid, e, (int)k, 1u, k + nlft};
     if (nlft == 1u) s_child[k].x = one_left;
-    else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = SahTask{b, mid, (int)k, 0u};
-    else if (nlft <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = SahTask{b, mid, (int)k, 0u};
-    else next[atomicAdd(&st->n_next, 1u)] = SahTask{b, mid, (int)k, 0u};
+    else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = L;
+    else if (nlft <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = L;
+    else next[atomicAdd(&st->n_next, 1u)] = L;
     if (nrgt == 1u) s_child[k].y = one_right;
-    else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = SahTask{mid, e, (int)k, 1u};
-    else if (nrgt <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = SahTask{mid, e, (int)k, 1u};
-    else next[atomicAdd(&st->n_next, 1u)] = SahTask{mid, e, (int)k, 1u};
+    else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = R;
+    else if (nrgt <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = R;
+    else next[atomicAdd(&st->n_next, 1u)] = R;
 }
 __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi,
                                                                   const SahTask* tasks, uint32_t n_tasks, SahTask* next, SahTask* next_big, SahTask* next_small,
                                                                   SahState* st, int2* s_child, float4* s_lo, float4* s_hi) {
     __shared__ int bins[MPT_SAH_WAVES][3][16][7];   // per wave: (lo xyz, hi xyz as ordered ints, primitive count) per axis and bin
+    __shared__ uint32_t s_push[MPT_SAH_WAVES][6];   // per wave: b, e, nlft, node, first item left / right (e = 0: nothing to push)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * MPT_SAH_WAVES + wv;
-    if (t >= n_tasks) return;
     const int TOP = 2 * n - 1;
-    const SahTask task = tasks[t];
+    SahTask task = SahTask{0u, 0u, -1, 0u, 0u};
+    if (t < n_tasks) task = tasks[t];
     const uint32_t b = task.b, e = task.e, m = e - b;
-    if (m == 1u) {   // (only the root task of a one-leaf tree comes here: children of one item are attached when they are split off)
-        if (lane == 0) sah_attach(st, s_child, task.parent, task.side, __float_as_int(in_lo[b].w));
-        return;
-    }
-    if (m == 2u) {   // two items: the node, nothing to choose (a third of all tasks, at the bottom of the tree)
-        if (lane == 0) {
-            const float4 l0 = in_lo[b], h0 = in_hi[b], l1 = in_lo[b + 1u], h1 = in_hi[b + 1u];
-            const uint32_t k2 = atomicAdd(&st->n_nodes, 1u);
-            s_lo[k2] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), __int_as_float(2));
-            s_hi[k2] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
-            s_child[k2] = make_int2(__float_as_int(l0.w), __float_as_int(l1.w));
-            sah_attach(st, s_child, task.parent, task.side, TOP + (int)k2);
-        }
-        return;
-    }
+    if (lane == 0) s_push[wv][1] = 0u;
+    if (m == 1u && lane == 0)   // (only the root task of a one-leaf tree: children of one item are attached when they are split off)
+        sah_attach(st, s_child, task.parent, task.side, __float_as_int(in_lo[b].w));
+    if (m >= 2u) {
     // pass 1: the node's box and the bounds of the box centres
     float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
           ch[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -216,14 +212,12 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
             cl[a] = fminf(cl[a], __shfl_xor(cl[a], off));
             ch[a] = fmaxf(ch[a], __shfl_xor(ch[a], off));
         }
-    uint32_t k = 0;
+    const uint32_t k = task.node;
     if (lane == 0) {
-        k = atomicAdd(&st->n_nodes, 1u);
         s_lo[k] = make_float4(nl[0], nl[1], nl[2], __int_as_float((int)m));   // (.w: items below the node)
         s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
         sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
     }
-    k = (uint32_t)__shfl((int)k, 0);
     // pass 2: bins
     for (uint32_t q = lane; q < 3u * 16u * 7u; q += 64u) {
         const uint32_t f = q % 7u;
@@ -313,7 +307,17 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
         nlft += (uint32_t)__popcll(lm);
         nrgt += (uint32_t)__popcll(rm);
     }
-    if (lane == 0) sah_push_children(st, s_child, next, next_big, next_small, b, e, nlft, k, one_left, one_right);
+    if (lane == 0) {
+        uint32_t* P = s_push[wv];
+        P[0] = b, P[1] = e, P[2] = nlft, P[3] = k, P[4] = (uint32_t)one_left, P[5] = (uint32_t)one_right;
+    }
+    }
+    // the children of the block's tasks, pushed by the lanes of ONE wave (see sah_push_children)
+    __syncthreads();
+    if (wv == 0 && lane < MPT_SAH_WAVES && s_push[lane][1] != 0u) {
+        const uint32_t* P = s_push[lane];
+        sah_push_children(st, s_child, next, next_big, next_small, P[0], P[1], P[2], P[3], (int)P[4], (int)P[5]);
+    }
 }
 
 // The same for the BIG tasks of a level (>= MPT_SAH_BIG items: the top ten levels of a 1 M-primitive tree, one to a few hundred
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
 // partition — run over CHUNKS of 2048 items, a workgroup each, whatever task a chunk belongs to:
 //   k_big_prep     the tasks' first chunk numbers (prefix over ceil(items / 2048)), accumulators reset          1 workgroup
 //   k_big_bounds   node box + bounds of the box centres, a chunk each, merged by atomics                          per chunk
-//   k_big_pick     bins from an evenly spaced sample of ~4096 items, the 45 planes priced, the node made          per task
+//   k_big_pick     bins from an evenly spaced sample of ~1024 items, the 45 planes priced, the node made          per task
 //   k_big_count    items that go left, per chunk                                                                  per chunk
 //   k_big_scatter  the partition: left from b upwards, right from e - 1 downwards, in item order (deterministic)  per chunk
 //   k_big_push     the children: tasks of the next level, or single items attached                                per task
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
 #define MPT_SAH_CHUNK 2048u
 #define MPT_SAH_CHUNK_THREADS 256u
 #ifndef MPT_SAH_SAMPLE_BIG
-#define MPT_SAH_SAMPLE_BIG 4096u
+#define MPT_SAH_SAMPLE_BIG 1024u
 #endif
 struct SahBig {
     int bounds[12];   // node box lo / hi, centre bounds lo / hi (ordered ints)
@@ -406,14 +410,21 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const floa
             cl[a] = fminf(cl[a], __shfl_xor(cl[a], off));
             ch[a] = fmaxf(ch[a], __shfl_xor(ch[a], off));
         }
-    if (lane == 0) {
-        int* B = big[t].bounds;
+    __shared__ int s_b[12];
+    if (tid < 12u) s_b[tid] = tid % 6u < 3u ? 0x7FFFFFFF : (int)0x80000000;
+    __syncthreads();
+    if (lane == 0)
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&B[a], f2o(nl[a]));
-            atomicMax(&B[3 + a], f2o(nh[a]));
-            atomicMin(&B[6 + a], f2o(cl[a]));
-            atomicMax(&B[9 + a], f2o(ch[a]));
+            atomicMin(&s_b[a], f2o(nl[a]));
+            atomicMax(&s_b[3 + a], f2o(nh[a]));
+            atomicMin(&s_b[6 + a], f2o(cl[a]));
+            atomicMax(&s_b[9 + a], f2o(ch[a]));
         }
+    __syncthreads();
+    if (tid < 12u) {   // (one set of global atomics per chunk)
+        int* B = big[t].bounds;
+        if (tid % 6u < 3u) atomicMin(&B[tid], s_b[tid]);
+        else atomicMax(&B[tid], s_b[tid]);
     }
 }
 __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahBig* big, SahState* st,
@@ -437,13 +448,13 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
     }
     __syncthreads();
     if (tid == 0) {
-        const uint32_t k = atomicAdd(&st->n_nodes, 1u);
+        const uint32_t k = task.node;
         G.k = k;
         s_lo[k] = make_float4(o2f(G.bounds[0]), o2f(G.bounds[1]), o2f(G.bounds[2]), __int_as_float((int)m));
         s_hi[k] = make_float4(o2f(G.bounds[3]), o2f(G.bounds[4]), o2f(G.bounds[5]), 0.0f);
         sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
     }
-    const uint32_t step = m > MPT_SAH_SAMPLE_BIG ? m / MPT_SAH_SAMPLE_BIG : 1u;   // (binned from a sample of ~4096 items: see k_sah_level)
+    const uint32_t step = m > MPT_SAH_SAMPLE_BIG ? m / MPT_SAH_SAMPLE_BIG : 1u;   // (binned from a sample of ~1024 items: see k_sah_level)
     for (uint32_t i = b + tid * step; i < e; i += MPT_SAH_BIG_THREADS * step) {
         const float4 l = in_lo[i], h = in_hi[i];
         const int cnt = __float_as_int(h.w);
@@ -495,12 +506,27 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
     }
 }
 // which side item i of the task goes to
-__device__ __forceinline__ bool sah_big_left(const SahBig& G, const SahTask& task, uint32_t i, float4 l, float4 h) {
-    if (G.pick < 0) return i - task.b < (task.e - task.b) / 2u;   // no plane separates the box centres: halves
-    const int a = G.pick / 15, sp = G.pick % 15;
-    int q = (int)((0.5f * (axis_of(l, a) + axis_of(h, a)) - G.cl[a]) * G.inv[a]);
+struct SahSplit {
+    int axis, split;   // axis < 0: no plane separates the box centres: halves
+    float cl, inv;
+    uint32_t b, half;
+};
+__device__ __forceinline__ SahSplit sah_split_of(const SahBig* G, const SahTask& task) {
+    SahSplit s;
+    const int pick = G->pick;
+    s.axis = pick < 0 ? -1 : pick / 15;
+    s.split = pick < 0 ? 0 : pick % 15;
+    s.cl = s.axis == 1 ? G->cl[1] : s.axis == 2 ? G->cl[2] : G->cl[0];
+    s.inv = s.axis == 1 ? G->inv[1] : s.axis == 2 ? G->inv[2] : G->inv[0];
+    s.b = task.b;
+    s.half = (task.e - task.b) / 2u;
+    return s;
+}
+__device__ __forceinline__ bool sah_big_left(const SahSplit& s, uint32_t i, float4 l, float4 h) {
+    if (s.axis < 0) return i - s.b < s.half;
+    int q = (int)((0.5f * (axis_of(l, s.axis) + axis_of(h, s.axis)) - s.cl) * s.inv);
     q = q < 0 ? 0 : (q > 15 ? 15 : q);
-    return q <= sp;
+    return q <= s.split;
 }
 __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float4* in_lo, const float4* in_hi, const SahTask* tasks, uint32_t n_big,
                                                                      const uint32_t* coff, const SahBig* big, uint32_t* chunk_left) {
@@ -509,10 +535,10 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float
     if (c >= coff[n_big]) return;
     const uint32_t t = sah_task_of_chunk(coff, n_big, c);
     const SahTask task = tasks[t];
-    const SahBig G = big[t];
+    const SahSplit G = sah_split_of(big + t, task);
     const uint32_t b = task.b + (c - coff[t]) * MPT_SAH_CHUNK, e = b + MPT_SAH_CHUNK < task.e ? b + MPT_SAH_CHUNK : task.e;
     uint32_t cnt = 0;
-    for (uint32_t i = b + tid; i < e; i += MPT_SAH_CHUNK_THREADS) cnt += sah_big_left(G, task, i, in_lo[i], in_hi[i]) ? 1u : 0u;
+    for (uint32_t i = b + tid; i < e; i += MPT_SAH_CHUNK_THREADS) cnt += sah_big_left(G, i, in_lo[i], in_hi[i]) ? 1u : 0u;
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (lane == 0) s_w[wv] = cnt;
     __syncthreads();
@@ -530,7 +556,7 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const flo
     if (c >= coff[n_big]) return;
     const uint32_t t = sah_task_of_chunk(coff, n_big, c);
     const SahTask task = tasks[t];
-    const SahBig G = big[t];
+    const SahSplit G = sah_split_of(big + t, task);
     const uint32_t j = c - coff[t];
     const uint32_t b = task.b + j * MPT_SAH_CHUNK, e = b + MPT_SAH_CHUNK < task.e ? b + MPT_SAH_CHUNK : task.e;
     // items that went left in the task's chunks before this one
@@ -551,7 +577,7 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const flo
         if (valid) {
             l = in_lo[i];
             h = in_hi[i];
-            left = sah_big_left(G, task, i, l, h);
+            left = sah_big_left(G, i, l, h);
         }
         const unsigned long long lm = __ballot(valid && left), rm = __ballot(valid && !left);
         if (lane == 0) {
@@ -599,7 +625,7 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
     static_assert(G == 8u || G == 16u, "MPT_SAH_SMALL: 8 or 16");
     const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / G, lane = threadIdx.x & 63u, gl = lane & (G - 1u), gbase = lane & ~(G - 1u);
     const int TOP = 2 * n - 1;
-    SahTask task = SahTask{0u, 0u, -1, 0u};
+    SahTask task = SahTask{0u, 0u, -1, 0u, 0u};
     if (t < n_tasks) task = tasks[t];
     bool live = gl < task.e - task.b;
     float4 l = make_float4(0, 0, 0, 0), h = l;
@@ -609,7 +635,7 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
     }
     uint32_t rb = 0u, re = task.e - task.b;   // this lane's range, in lanes of the group
     int parent = task.parent;
-    uint32_t side = task.side;
+    uint32_t side = task.side, nb = task.node;   // (nb: the node this lane's range makes)
     for (uint32_t round = 0; round < G; ++round) {
         if (__ballot(live) == 0ull) break;
         // the range's box, the bounds of its box centres
@@ -630,14 +656,12 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
                 }
         }
         const uint32_t m = re - rb;
-        uint32_t k = 0;
+        const uint32_t k = nb;
         if (live && gl == rb) {
-            k = atomicAdd(&st->n_nodes, 1u);
             s_lo[k] = make_float4(nl[0], nl[1], nl[2], __int_as_float((int)m));
             s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
             sah_attach(st, s_child, parent, side, TOP + (int)k);
         }
-        k = (uint32_t)__shfl((int)k, (int)(gbase + rb));
         // bins of this lane's item; the plane behind each of them, priced over the range
         float inv[3];
         int q3[3];
@@ -708,8 +732,8 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
         // (a lane stays in its old range, so the range's nlft and k are still the ones it knows)
         if (live) {
             parent = (int)k;
-            if (gl < rb + nlft) re = rb + nlft, side = 0u;
-            else rb = rb + nlft, side = 1u;
+            if (gl < rb + nlft) re = rb + nlft, side = 0u, nb = k + 1u;
+            else rb = rb + nlft, side = 1u, nb = k + nlft;
             if (re - rb == 1u) {   // alone: attached at once
                 if (side == 0u) s_child[k].x = __float_as_int(l.w);
                 else s_child[k].y = __float_as_int(l.w);

@@ -182,8 +182,9 @@ def test_build_and_upload_small_inputs_spheres_and_rays(gpu_ctx):
 
 
 def test_build_and_upload_one_million_primitives_is_fast(gpu_ctx, tmp_path):
-    """SURVEY 8 f-1 at config-4 size: 1,000,003 primitives ready to render in tens of milliseconds of wall time (the reference's
-    builder: 8.2 s on one core; mpt_build_bvh + mpt_upload_scene: 0.55 s), and the render agrees with the reference-order one."""
+    """SURVEY 8 f-1 at config-4 size: 1,000,003 primitives ready to render in about ten milliseconds of wall time, the 80 MB
+    upload included (measured 8.6-8.9 ms, 4.5-4.8 of them on the device; the reference's builder: 8.2 s on one core;
+    mpt_build_bvh + mpt_upload_scene: 0.55 s), and the render agrees with the reference-order one."""
     import time
     from metalpathtracer_amd import capi, host
     from test_gpu_parity import _heightfield_obj
@@ -207,7 +208,7 @@ def test_build_and_upload_one_million_primitives_is_fast(gpu_ctx, tmp_path):
         best = min(best, time.perf_counter() - t0)
     info = gpu_ctx.accel_info()
     assert info["ordered_ok"] == 1 and info["always_spheres"] == 3 and info["nodes"] > 100000
-    assert best < 0.055, "1 M primitives took %.1f ms of wall time (device %.1f ms)" % (best * 1e3, ms)
+    assert best < 0.020 and ms < 12.0, "1 M primitives took %.1f ms of wall time (device %.1f ms)" % (best * 1e3, ms)
     W, H = 320, 180
     gpu_ctx.resize(W, H)
     gpu_ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
