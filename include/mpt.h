@@ -210,21 +210,24 @@ int mpt_trace_rays_ordered(mpt_ctx* ctx, const float* origins, const float* dire
 int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 
 /* BVH construction on the GPU — stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,
- * 195-317: sequential full-sweep SAH, 8.2 s for 1 M primitives): a linear BVH (63-bit Morton codes, radix sort, Karras'
- * radix tree, bottom-up refit) with leaves of <= 2 primitives (MPT_LBVH_LEAF: 1..8), written in the REFERENCE's buffer format so that
+ * 195-317: sequential full-sweep SAH, 8.2 s for 1 M primitives): a top-down binned SAH over the primitives, built level by
+ * level on the device (16 bins over the box centres, cost = area * primitives: the tree of the host's binned builder), with
+ * leaves of <= 2 primitives (MPT_LBVH_LEAF: 1..8), written in the REFERENCE's buffer format so that
  * mpt_upload_scene (and the reference's shader, and the oracle) can consume it: bvh_out = 2 float4 per node as
- * Scene::createBVHBuffer returns them (root = node 0), prim_idx_out = Scene::createPrimitiveIndexBuffer.
+ * Scene::createBVHBuffer returns them (root = node 0), prim_idx_out = Scene::createPrimitiveIndexBuffer.  The same input
+ * gives the same arrays on every call.  MPT_GPU_BUILD = ploc | lbvh selects the two earlier builders instead (63-bit
+ * Morton codes + radix sort, then nearest-neighbour clustering or Karras' radix tree: slower to render by 1-16 %).
  * prims: the 3-float4-per-primitive array of Scene::createTransformsBuffer (host memory, already sorted spheres first as
  * Scene::buildBVH does, Scene.h:72-75).  bvh_capacity_nodes >= 2 * n_prims - 1 is always enough.  device_ms_out
  * (optional): HIP-event time of the build kernels.  Parent boxes are exact unions of child boxes.                      */
 int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims, float* bvh_out, uint64_t bvh_capacity_nodes,
                   uint64_t* n_nodes_out, int32_t* prim_idx_out, double* device_ms_out);
 
-/* Build -> render without the host: the same linear BVH, built on the device from the caller's primitive and material arrays
+/* Build -> render without the host: the same tree, built on the device from the caller's primitive and material arrays
  * (prims: 3 float4 each as Scene::createTransformsBuffer returns them, mats: 2 float4 each as Scene::createMaterialsBuffer)
  * and turned ON THE DEVICE into everything mpt_upload_scene derives on the host — the threaded reference-order tree, the
  * leaf-ordered primitive records, the de-duplicated materials, the product's own 4-wide tree — so that the scene is ready
- * to render when the call returns (1 M primitives: tens of milliseconds; mpt_build_bvh + mpt_upload_scene: 0.55 s).  Stands
+ * to render when the call returns (1 M primitives: 9 ms, 4 of them the upload; mpt_build_bvh + mpt_upload_scene: 0.55 s).  Stands
  * for Scene::buildBVH + the four packers + Renderer::updateVisibleScene / buildBuffers (R/Scene/Scene.h:71-93,99-167,195-317,
  * R/Renderer/Renderer.cpp:127-146,199-215).  mpt_download_bvh returns that tree in the REFERENCE's buffer format (as
  * mpt_build_bvh does): what the reference's shader — and the oracle — would walk to produce the same image.                 */

@@ -37,8 +37,9 @@ public:
     enum class BuildMode {
         ReferenceSweep,  // full-sweep SAH keyed on data0[axis], leaf <= 8 (R/Scene/Scene.h:195-317): same tree
         BinnedCentroid,  // 16-bin SAH on centroids, O(n log n): for large scenes; image-equivalent, not tree-equal
-        GpuLbvh          // linear BVH built on the GPU (mpt_build_bvh: Morton sort + Karras tree, leaves <= 8); needs a
-                         // device (MPT_BUILD_DEVICE, default 0) and throws without one — there is no CPU fallback
+        GpuLbvh          // built on the GPU (mpt_build_bvh: top-down binned SAH, leaves <= 2; MPT_GPU_BUILD = ploc | lbvh for the
+                         // Morton-code builders); needs a device (MPT_BUILD_DEVICE, default 0) and throws without one — there
+                         // is no CPU fallback
     };
 
     Scene() = default;

@@ -224,12 +224,10 @@ __global__ void k_items(int n, const int2* range, const uint32_t* is_leaf, const
 // leaf leaves its spheres out, and may be empty) — so one bottom-up pass from the leaves refits them, and splices out what is
 // empty: eff[node] = the node that stands for the sub-tree (the leaf; TOP + node for an inner node with two non-empty
 // children; the other child's eff when one is empty; -1 when both are).
-__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// (What one thread hands to another here goes through agent-scope stores and loads — past the L1 and the XCD's L2 — and the
-//  arrival counter is bumped behind a WORKGROUP-scope fence, which only waits for those stores.  __threadfence() would write
-//  the whole L2 back, every thread, every level: 5.2 ms at 1 M primitives against 0.3.)
+using mpt_lbvh::ld_agent;
+using mpt_lbvh::st4;
+using mpt_lbvh::st_agent;
+// (hand-over between threads as in mpt_lbvh.h k_refit: agent-scope stores and loads, workgroup-scope fences)
 __global__ void k_own_tree(int n, const int* parent, const int2* child, const uint32_t* is_leaf, const float4* olo, const float4* ohi, int* eff, float4* s_lo,
                            float4* s_hi, int2* s_child, int* arrived, SahState* st) {
     const int leaf = blockIdx.x * blockDim.x + threadIdx.x, TOP = 2 * n - 1;
@@ -251,10 +249,8 @@ __global__ void k_own_tree(int n, const int* parent, const int2* child, const ui
         if (ex >= 0 && ey >= 0) {
             const float4 a0 = ex < TOP ? olo[ex] : mpt_lbvh::ld4(s_lo + (ex - TOP)), a1 = ex < TOP ? ohi[ex] : mpt_lbvh::ld4(s_hi + (ex - TOP));
             const float4 b0 = ey < TOP ? olo[ey] : mpt_lbvh::ld4(s_lo + (ey - TOP)), b1 = ey < TOP ? ohi[ey] : mpt_lbvh::ld4(s_hi + (ey - TOP));
-            float* L = (float*)(s_lo + p);
-            float* H = (float*)(s_hi + p);
-            st_agent(L, fminf(a0.x, b0.x)); st_agent(L + 1, fminf(a0.y, b0.y)); st_agent(L + 2, fminf(a0.z, b0.z)); st_agent(L + 3, 0.0f);
-            st_agent(H, fmaxf(a1.x, b1.x)); st_agent(H + 1, fmaxf(a1.y, b1.y)); st_agent(H + 2, fmaxf(a1.z, b1.z)); st_agent(H + 3, 0.0f);
+            st4(s_lo + p, fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z));
+            st4(s_hi + p, fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z));
             s_child[p] = make_int2(ex, ey);
             e = TOP + p;
         } else {

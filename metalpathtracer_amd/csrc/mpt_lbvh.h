@@ -1,7 +1,10 @@
-// mpt_lbvh.h — BVH construction ON THE GPU: a linear BVH (63-bit Morton codes of the primitive
-// centroids, radix sort, Karras' parallel radix-tree construction, bottom-up refit) collapsed to leaves of <= 2
-// primitives (MPT_LBVH_LEAF = 1..8; the closest-first pipeline tests every primitive of a leaf it enters, so small
-// leaves pay there: bunny x20 11.1 / 11.4 / 11.7 / 11.1 Grays/s with 4 / 3 / 2 / 1) and written in the REFERENCE's buffer format (SURVEY App. D buf 0 / buf 6):
+// mpt_lbvh.h — BVH construction ON THE GPU: a binary tree over the primitives, by one of three builders —
+//   sah   (default) top-down binned SAH, level by level (mpt_sah.h): the host binned builder's tree, 1 M primitives in 4 ms
+//   ploc  63-bit Morton codes of the primitive centroids, radix sort, then rounds of nearest-neighbour clustering
+//   lbvh  the same sort, then Karras' parallel radix-tree construction and a bottom-up refit
+// — collapsed to leaves of <= 2 primitives (MPT_LBVH_LEAF = 1..8; the closest-first pipeline tests every primitive of a leaf
+// it enters, so small leaves pay there: bunny x20 12.5 / 13.2 / 12.9 / 12.5 Grays/s with 1 / 2 / 3 / 4) and written in the
+// REFERENCE's buffer format (SURVEY App. D buf 0 / buf 6):
 //   node = (bmin.xyz, bits(leftFirst)) (bmax.xyz, bits(count));  count > 0: leaf, primitiveIndices[leftFirst ..
 //   leftFirst+count);  count <= 0: internal, left child = leftFirst, right child = -count;  root = node 0.
 // It stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,195-317: a sequential
@@ -9,8 +12,6 @@
 // (sphere: centre -+ radius; triangle: min / max of the vertices) and parent boxes are unions of child boxes, so boxes
 // nest exactly (which the closest-first pipeline requires).  The tree topology is not a parity target: the
 // oracle renders the same image from these arrays as the HIP pipelines do (tests/test_gpu_lbvh.py).
-// The quality of the inner nodes hardly matters to the default pipeline: it builds its own 4-wide tree over the LEAVES
-// (mpt_accel.h); what it takes from here is the partition into leaves — Morton-contiguous runs of <= 8 primitives.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -130,11 +131,24 @@ __global__ void k_hierarchy(const unsigned long long* keys, int n, int2* child, 
     if (i == 0) parent[0] = -1;
 }
 
+// What one thread hands to another inside a kernel goes through agent-scope stores and loads — past the L1 and the XCD's L2 —
+// and the arrival counter is bumped behind a WORKGROUP-scope fence, which only waits for those stores.  (__threadfence()
+// writes the whole L2 back, every thread, every level: 5.2 ms for a 1 M-primitive refit against 0.2.)
 __device__ __forceinline__ float4 ld4(const float4* p) {
     const float* f = (const float*)p;
     return make_float4(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                        __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                        __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0.0f);
+}
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st4(float4* p, float x, float y, float z) {
+    float* f = (float*)p;
+    st_agent(f, x);
+    st_agent(f + 1, y);
+    st_agent(f + 2, z);
+    st_agent(f + 3, 0.0f);
 }
 // bottom-up boxes: the second thread to arrive at a node computes it
 __global__ void k_refit(const uint32_t* vals, const float4* blo, const float4* bhi, int n, const int2* child, const int* parent,
@@ -142,19 +156,18 @@ __global__ void k_refit(const uint32_t* vals, const float4* blo, const float4* b
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const uint32_t prim = vals[p];
-    nlo[(n - 1) + p] = blo[prim];
-    nhi[(n - 1) + p] = bhi[prim];
-    __threadfence();
+    const float4 l = blo[prim], h = bhi[prim];
+    st4(nlo + (n - 1) + p, l.x, l.y, l.z);
+    st4(nhi + (n - 1) + p, h.x, h.y, h.z);
     int node = parent[(n - 1) + p];
     while (node >= 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (atomicAdd(&arrived[node], 1) == 0) return;  // the sibling subtree is not finished yet
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int2 c = child[node];
-        // the sibling's box was written by another CU: read it past this CU's L1 (agent-scope loads)
         const float4 a0 = ld4(nlo + c.x), a1 = ld4(nhi + c.x), b0 = ld4(nlo + c.y), b1 = ld4(nhi + c.y);
-        nlo[node] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.0f);
-        nhi[node] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.0f);
-        __threadfence();
+        st4(nlo + node, fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z));
+        st4(nhi + node, fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z));
         node = parent[node];
     }
 }
