@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "mpt_accel.h"
 #include "mpt_device.h"
@@ -490,7 +492,11 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     SahState* d_st;
     int2* s_child;
     float4 *s_lo, *s_hi;
-    if (builder == mpt_lbvh::BUILDER_SAH && n > 2) {
+    // (the builder's own tree serves when no sphere sits on the always list: the spheres' boxes — a ground sphere of radius
+    //  1e4 — shaped its top splits, and the own tree leaves them out; MPT_OWN_TREE = refit | sah forces either way)
+    bool refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && (n_spheres_hint == 0 || !use_always);
+    if (const char* e = getenv("MPT_OWN_TREE")) refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && strcmp(e, "refit") == 0;
+    if (refit) {
         int *eff, *arrived;
         MPT_LB(sc.alloc(&d_st, 1));
         MPT_LB(sc.alloc(&eff, nn));

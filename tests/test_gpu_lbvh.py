@@ -79,7 +79,11 @@ def test_gpu_built_tree_is_well_formed_and_renders_the_oracle_image(gpu_ctx, nam
 def test_gpu_build_small_inputs_and_determinism(gpu_ctx, builder, monkeypatch):
     """1, 2, 3, 9 primitives (a single leaf; the smallest trees), duplicates (equal Morton codes, no separating plane), and the
     same arrays twice: the top-down builder numbers its nodes by atomics and must still write the same arrays every time."""
-    monkeypatch.setenv("MPT_GPU_BUILD", builder)
+    # ("sah+refit" / "sah+sah": the own 4-wide tree from the builder's tree refitted, or from a second SAH over the leaves —
+    #  by default the first when the scene has no sphere for the always list, the second otherwise, as in these four scenes)
+    monkeypatch.setenv("MPT_GPU_BUILD", builder.split("+")[0])
+    if "+" in builder:
+        monkeypatch.setenv("MPT_OWN_TREE", builder.split("+")[1])
     rng = np.random.default_rng(3)
     for n in (1, 2, 3, 8, 9, 17, 100, 3000):
         prims = np.zeros((n, 12), np.float32)
@@ -97,7 +101,7 @@ def test_gpu_build_small_inputs_and_determinism(gpu_ctx, builder, monkeypatch):
         assert (n <= 2) == (bvh.shape[0] == 1)                       # leaves hold <= 2 primitives by default
 
 
-@pytest.mark.parametrize("builder", ["sah", "ploc", "lbvh"])
+@pytest.mark.parametrize("builder", ["sah", "sah+refit", "sah+sah", "ploc", "lbvh"])
 @pytest.mark.parametrize("name,bsdf", [("scene.xml", 0), ("glass.xml", 1), ("bunny20.xml", 0), ("cornell.xml", 0)])
 def test_build_and_upload_renders_the_oracle_image_of_its_own_tree(gpu_ctx, name, bsdf, builder, monkeypatch):
     """mpt_build_and_upload: build -> render without the host, with each of the three binary-tree builders (top-down binned

@@ -18,6 +18,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d
 cd $ROOT
 find $OUT/bench_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
 find $OUT/devb_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_devbuild_kernel_stats.csv
+python3 tools/trace_timeline.py $(find $OUT/devb_trace -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_devbuild_timeline.txt 2>&1 || exit 1
 python3 bench.py --steps 8 --warmup 2 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 COUNT=1 SPP=128 JSON_OUT=$OUT/${TAG}_step_table.json MPT_LIB=$LIB/libmpt_hip_wavetimes.so timeout -k 10 300 python3 tools/gpu_wave_times.py > $OUT/${TAG}_step_table.txt 2>&1 || exit 1
 BVH=1 JSON_OUT=$OUT/${TAG}_ot_times_bunny20.json MPT_LIB=$LIB/libmpt_hip_times.so timeout -k 10 300 python3 tools/gpu_ot_times.py bunny20.xml 64 > $OUT/${TAG}_ot_times_bunny20.txt 2>&1 || exit 1
