@@ -52,9 +52,10 @@ def parse():
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "scene.xml"))
     ap.add_argument("--pipeline", default=os.environ.get("MPT_BENCH_PIPELINE", "default"),
                     choices=["default", "wavefront", "megakernel", "wavelocal", "ordered"])
-    ap.add_argument("--bvh", default="reference", choices=["reference", "binned", "gpu", "device"],
-                    help="tree builder: the reference's sweep SAH (default: the drop-in behaviour), the host binned SAH, the GPU builder through "
-                         "the host (mpt_build_bvh + mpt_upload_scene), or build -> render on the device (mpt_build_and_upload)")
+    ap.add_argument("--bvh", default="device", choices=["reference", "binned", "gpu", "device"],
+                    help="tree builder: build -> render on the device (mpt_build_and_upload, the default: binned SAH, what the Renderer's "
+                         "throughput mode does), the reference's sweep SAH (the drop-in tree), the host binned SAH, or the GPU builder through "
+                         "the host (mpt_build_bvh + mpt_upload_scene)")
     ap.add_argument("--slots", type=int, default=0, help="wavefront width (ray slots per iteration), 0 = default")
     ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,7 +152,7 @@ def extra_workloads(ctx, capi, host, depth):
     the driver's record carries them.  HIP-event time of the whole render, best of two after a warm-up."""
     import time
     out = []
-    for name, xml, builder, cam in (("cornell.xml", "cornell.xml", "reference", CORNELL_CAM), ("bunny20.xml", "bunny20.xml", "device", None)):
+    for name, xml, builder, cam in (("cornell.xml", "cornell.xml", "device", CORNELL_CAM), ("bunny20.xml", "bunny20.xml", "device", None)):
         sc = host.Scene()
         st, log = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", xml), sc)
         if st != 0:
@@ -219,16 +220,10 @@ def main():
     if st != 0:
         sys.exit("cannot load %s: %s" % (args.scene, log))
     ctx = capi.Context(local)
-    if args.bvh == "device":
-        sc.buildBVH(host.BVH_REFERENCE_SWEEP)        # (sorts the primitives as every builder does; this tree is not used)
-        prims, mats = sc.packed_primitives()
-        ctx.build_and_upload(prims, mats)
-        bvh, idx = ctx.download_bvh()                # the tree in the reference's format: what the CPU leg walks
-        buffers = (bvh, prims, mats, idx)
-    else:
-        sc.buildBVH({"reference": host.BVH_REFERENCE_SWEEP, "binned": host.BVH_BINNED_CENTROID, "gpu": host.BVH_GPU_LBVH}[args.bvh])
-        buffers = sc.buffers()
-        ctx.upload_scene(*buffers)
+    # (device: build -> render on the device, mpt_build_and_upload — what the Renderer's throughput mode does; the tree comes
+    #  back in the reference's format for the CPU leg, which walks the same arrays)
+    buffers = host.make_ready(ctx, sc, {"reference": host.BVH_REFERENCE_SWEEP, "binned": host.BVH_BINNED_CENTROID, "gpu": host.BVH_GPU_LBVH,
+                                        "device": host.BVH_DEVICE}[args.bvh])
     P, T = sc.getPrimitiveCount(), sc.getTriangleCount()
     W, H = args.width, args.height
     ctx.resize(W, H)

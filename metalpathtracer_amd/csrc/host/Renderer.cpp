@@ -85,10 +85,10 @@ void Renderer::updateVisibleScene() {
     // The drop-in default is the reference's own sweep builder (R/Scene/Scene.h:195-317, the very same tree): with the
     // literal RNG and the frame protocol the reference's answer on ties and inconsistent hits depends on the visit order,
     // so the tree is part of the behaviour.  A caller that wants throughput asks for it (setBuildMode / MPT_BVH_MODE):
-    // "auto" = from MPT_AUTO_ORDERED_PRIMS (8192) primitives mpt_build_and_upload, build -> render on the device with the
-    // same binned-SAH algorithm as the host's: bunny x20 ready in 4.5 ms instead of 105 (host binned SAH + upload), 1 M
-    // primitives in 9 ms instead of 890, at 98-100 % of the host tree's rays per second; "binned" = the host's 16-bin SAH
-    // builder; "gpu" = the device build for any scene size.
+    // "auto" / "gpu" = mpt_build_and_upload, build -> render on the device with the host binned builder's algorithm: scene.xml
+    // renders 10 % faster than on the reference's tree (leaves of <= 8 for the reference-order kernel), bunny x20 is ready in
+    // 5 ms instead of 105 (host binned SAH + upload), 1 M primitives in 9 ms instead of 890, at 99-100 % of the host tree's
+    // rays per second; "binned" = the host's 16-bin SAH builder.
     int want = buildMode_;
     if (const char* e = std::getenv("MPT_BVH_MODE")) {
         if (std::strcmp(e, "reference") == 0) want = BUILD_REFERENCE;
@@ -96,7 +96,7 @@ void Renderer::updateVisibleScene() {
         else if (std::strcmp(e, "gpu") == 0) want = BUILD_GPU;
         else if (std::strcmp(e, "auto") == 0) want = BUILD_AUTO;
     }
-    if (want == BUILD_AUTO) want = scene_->getPrimitiveCount() >= MPT_AUTO_ORDERED_PRIMS ? BUILD_GPU : BUILD_REFERENCE;
+    if (want == BUILD_AUTO) want = BUILD_GPU;
     const Scene::BuildMode mode = want == BUILD_BINNED ? Scene::BuildMode::BinnedCentroid
                                   : want == BUILD_GPU  ? Scene::BuildMode::GpuLbvh
                                                        : Scene::BuildMode::ReferenceSweep;

@@ -1527,6 +1527,15 @@ static int gpu_builder() {
     return mpt_lbvh::BUILDER_SAH;
 }
 
+// Primitives per leaf of the GPU builders (MPT_LBVH_LEAF = 1..8 overrides).  Scenes that MPT_PIPE_AUTO renders with the
+// reference-order kernel (fewer than MPT_AUTO_ORDERED_PRIMS primitives: tree and primitives live in LDS there) get leaves of
+// <= 8 — scene.xml: 19.3 ms per 256 spp against 20.8 with leaves of 2 and 21.3 on the reference's own tree; the closest-first
+// kernel tests every primitive of a leaf it enters and wants them small (bunny x20: 12.5 Grays/s with 4, 13.2 with 2).
+static int gpu_leaf_max(uint64_t n_prims) {
+    if (const char* lm = getenv("MPT_LBVH_LEAF")) return std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
+    return n_prims < MPT_AUTO_ORDERED_PRIMS ? 8 : 2;
+}
+
 // ---- build -> render without the host (mpt_devbuild.h) -------------------------------------------------------------------------
 static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* mats, uint64_t n_prims, double* device_ms_out) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
@@ -1545,8 +1554,7 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     HIPCHK(d_m.alloc((size_t)n * 32));
     HIPCHK(hipMemcpyAsync(d_p.p, prims, (size_t)n * 48, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_m.p, mats, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
-    int leaf_max = 2;
-    if (const char* lm = getenv("MPT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
+    const int leaf_max = gpu_leaf_max(n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) {
@@ -1700,8 +1708,7 @@ extern "C" int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims,
         if (bvh_capacity_nodes < 2 * n_prims - 1) return fail(ctx, MPT_ERR_INVALID_ARG, "bvh_out must hold 2 * n_prims - 1 nodes");
         HIPCHK(hipSetDevice(ctx->device));
         float ms = 0.0f;
-        int leaf_max = 2;
-        if (const char* lm = getenv("MPT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
+        const int leaf_max = gpu_leaf_max(n_prims);
         hipError_t e = mpt_lbvh::build(ctx->stream, prims, (uint32_t)n_prims, leaf_max, gpu_builder(), bvh_out, n_nodes_out, prim_idx_out, &ms, &ctx->build_pool);
         if (e != hipSuccess) return fail(ctx, MPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
         if (device_ms_out) *device_ms_out = ms;

@@ -174,6 +174,27 @@ class SceneLoader:
         return st, log.value.decode(errors="replace")
 
 
+BVH_DEVICE = 3   # make_ready only: build -> render on the device (mpt_build_and_upload); 0..2 are Scene::buildBVH's modes
+
+
+def make_ready(ctx, scene, bvh=BVH_REFERENCE_SWEEP):
+    """The scene ready to render on `ctx` with the tree builder `bvh`: Scene::buildBVH + mpt_upload_scene for the host
+    builders (0 reference sweep, 1 binned SAH, 2 GPU tree copied through the host), mpt_build_and_upload for BVH_DEVICE.
+    Returns the (bvh, prims, mats, prim_idx) arrays in the reference's buffer format — for BVH_DEVICE the tree comes back
+    from the device (mpt_download_bvh): what the oracle walks to render the same image."""
+    if bvh == BVH_DEVICE:
+        if scene.getBVHNodeCount() == 0:
+            scene.buildBVH(BVH_REFERENCE_SWEEP)      # (sorts the primitives spheres first, as every builder does; the tree is not used)
+        prims, mats = scene.packed_primitives()
+        ctx.build_and_upload(prims, mats)
+        tree, idx = ctx.download_bvh()
+        return tree, prims, mats, idx
+    scene.buildBVH(bvh)
+    buffers = scene.buffers()
+    ctx.upload_scene(*buffers)
+    return buffers
+
+
 def camera_reset():
     """Camera::reset() (R/Renderer/Camera.h:24-32)."""
     pos, fwd, up = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()

@@ -439,23 +439,30 @@ def test_cli_mpt_render_matches_golden(tmp_path):
     from conftest import GOLDEN, ROOT
     exe = os.path.join(ROOT, "metalpathtracer_amd", "lib", "mpt_render")
     out = str(tmp_path / "o.pfm")
-    r = subprocess.run([exe, "--scene", scene_path("scene.xml"), "--width", "96", "--height", "54", "--spp", "8",
-                        "--depth", "8", "--seed", "1", "--out", out], capture_output=True, text=True)
+    base = [exe, "--scene", scene_path("scene.xml"), "--width", "96", "--height", "54", "--spp", "8", "--depth", "8", "--seed", "1", "--out", out]
+    want = np.load(os.path.join(GOLDEN, "scene_philox_8spp_d8.npy"))
+    hdr = b"PF\n96 54\n-1.0\n"
+    # a batch render takes the device builder (--bvh auto): another tree than the fixture's, the same image up to the rays
+    # whose answer depends on the visit order (ties)
+    r = subprocess.run(base, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(out, "rb").read()
+    img = np.frombuffer(raw[len(hdr):], np.float32).reshape(54, 96, 3)[::-1]
+    assert pixel_l2(img, want[..., :3] * np.float32(0.125)) < L2_TOL
+    r = subprocess.run(base + ["--bvh", "reference"], capture_output=True, text=True)   # the reference's own tree: bit for bit
     assert r.returncode == 0, r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     info = json.loads(line)
     raw = open(out, "rb").read()
-    hdr = b"PF\n96 54\n-1.0\n"
     assert raw.startswith(hdr)
     img = np.frombuffer(raw[len(hdr):], np.float32).reshape(54, 96, 3)[::-1]
-    want = np.load(os.path.join(GOLDEN, "scene_philox_8spp_d8.npy"))
     manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))["scene_philox_8spp_d8"]
     assert info["rays"] == manifest["counters"]["rays"] and info["paths"] == 96 * 54 * 8
     np.testing.assert_array_equal(img, want[..., :3] * np.float32(0.125))
     # Cornell through the camera flags
     r = subprocess.run([exe, "--scene", scene_path("cornell.xml"), "--width", "64", "--height", "64", "--spp", "16",
                         "--depth", "32", "--seed", "1", "--camera-pos", "0,1,3.4", "--camera-dir", "0,0,-1",
-                        "--camera-up", "0,1,0", "--vfov", "40", "--out", out], capture_output=True, text=True)
+                        "--camera-up", "0,1,0", "--vfov", "40", "--bvh", "reference", "--out", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     raw = open(out, "rb").read()
     hdr = b"PF\n64 64\n-1.0\n"

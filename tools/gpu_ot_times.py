@@ -7,8 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 name = sys.argv[1] if len(sys.argv) > 1 else "scene.xml"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", name), sc); assert st == 0
-sc.buildBVH(int(os.environ.get("BVH", "0")))
-ctx = capi.Context(0); ctx.upload_scene(*sc.buffers())
+ctx = capi.Context(0); host.make_ready(ctx, sc, int(os.environ.get("BVH", "0")))
 W, H = 1920, 1080
 ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
 L = capi.load()

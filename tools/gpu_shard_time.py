@@ -4,8 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from metalpathtracer_amd import capi, host
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", "scene.xml"), sc); assert st == 0
-sc.buildBVH()
-ctx = capi.Context(0); ctx.upload_scene(*sc.buffers())
+ctx = capi.Context(0); host.make_ready(ctx, sc, int(os.environ.get("BVH", str(host.BVH_DEVICE))))   # (the tree bench.py renders on)
 W, H = 1920, 1080
 ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
 base = None

@@ -5,8 +5,7 @@ from metalpathtracer_amd import capi, host
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 scene = os.environ.get("SCENE", "scene.xml")
 sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", scene), sc); assert st == 0
-sc.buildBVH(int(os.environ.get("BVH", "0")))
-ctx = capi.Context(0); ctx.upload_scene(*sc.buffers())
+ctx = capi.Context(0); host.make_ready(ctx, sc, int(os.environ.get("BVH", "0")))   # 0 reference, 1 binned, 2 GPU through the host, 3 device build
 W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
 ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
 spp = int(os.environ.get("SPP", "16")); pipe = int(os.environ.get("PIPE", "1")); depth = int(os.environ.get("DEPTH", "8"))

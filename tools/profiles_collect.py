@@ -4,10 +4,10 @@ import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-notes = {"wl": ("pmc_wavelocal", "scene.xml 1920x1080, 256 spp, depth 8, reference tree: the default bench.py step."),
+notes = {"wl": ("pmc_wavelocal", "scene.xml 1920x1080, 256 spp, depth 8, device-built binned-SAH tree (leaves <= 8): the default bench.py step."),
          "ot": ("pmc_ordered", "scene.xml 1920x1080, 256 spp, depth 8, reference tree, MPT_PIPE_ORDERED."),
-         "otb": ("pmc_ordered_bunny20", "bunny x20 (99,362 primitives, host binned-SAH tree) 1920x1080, 64 spp, depth 8, MPT_PIPE_ORDERED."),
-         "wlb": ("pmc_wavelocal_bunny20", "bunny x20 (99,362 primitives, host binned-SAH tree) 1920x1080, 64 spp, depth 8, MPT_PIPE_WAVELOCAL.")}
+         "otb": ("pmc_ordered_bunny20", "bunny x20 (99,362 primitives, device-built binned-SAH tree) 1920x1080, 64 spp, depth 8, MPT_PIPE_ORDERED."),
+         "wlb": ("pmc_wavelocal_bunny20", "bunny x20 (99,362 primitives, device-built binned-SAH tree) 1920x1080, 64 spp, depth 8, MPT_PIPE_WAVELOCAL.")}
 for k, (name, note) in notes.items():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_finalize.py"), tag + k, os.path.join(P, "%s_%s.json" % (tag, name)), note],
                           stdout=subprocess.DEVNULL)

@@ -5,11 +5,11 @@
 # `python tools/profiles_collect.py <tag>` afterwards (here) to turn it into profiles/<tag>_*.
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}; OUT=$ROOT/gpurun_out; mkdir -p $OUT; LIB=$ROOT/metalpathtracer_amd/lib
-PIPE=2 bash tools/pmc_round.sh ${TAG}wl k_wavelocal > $OUT/${TAG}_pmc_wl.log 2>&1 || exit 1
+BVH=3 PIPE=2 bash tools/pmc_round.sh ${TAG}wl k_wavelocal > $OUT/${TAG}_pmc_wl.log 2>&1 || exit 1
 PIPE=3 bash tools/pmc_round.sh ${TAG}ot k_ordered > $OUT/${TAG}_pmc_ot.log 2>&1 || exit 1
-SCENE=bunny20.xml BVH=1 SPP=64 PIPE=3 bash tools/pmc_round.sh ${TAG}otb k_ordered > $OUT/${TAG}_pmc_otb.log 2>&1 || exit 1
-SCENE=bunny20.xml BVH=1 SPP=64 PIPE=2 bash tools/pmc_round.sh ${TAG}wlb k_wavelocal > $OUT/${TAG}_pmc_wlb.log 2>&1 || exit 1
-SCENE=bunny20.xml BVH=1 SPP=64 PIPE=3 bash tools/pmc_mem.sh ${TAG}otb k_ordered > $OUT/${TAG}_mem_otb.log 2>&1 || exit 1
+SCENE=bunny20.xml BVH=3 SPP=64 PIPE=3 bash tools/pmc_round.sh ${TAG}otb k_ordered > $OUT/${TAG}_pmc_otb.log 2>&1 || exit 1
+SCENE=bunny20.xml BVH=3 SPP=64 PIPE=2 bash tools/pmc_round.sh ${TAG}wlb k_wavelocal > $OUT/${TAG}_pmc_wlb.log 2>&1 || exit 1
+SCENE=bunny20.xml BVH=3 SPP=64 PIPE=3 bash tools/pmc_mem.sh ${TAG}otb k_ordered > $OUT/${TAG}_mem_otb.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/bench_trace
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -o b -- python3 $ROOT/bench.py --steps 8 --warmup 2 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err || exit 1
@@ -21,7 +21,7 @@ find $OUT/devb_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT
 python3 tools/trace_timeline.py $(find $OUT/devb_trace -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_devbuild_timeline.txt 2>&1 || exit 1
 python3 bench.py --steps 8 --warmup 2 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 COUNT=1 SPP=128 JSON_OUT=$OUT/${TAG}_step_table.json MPT_LIB=$LIB/libmpt_hip_wavetimes.so timeout -k 10 300 python3 tools/gpu_wave_times.py > $OUT/${TAG}_step_table.txt 2>&1 || exit 1
-BVH=1 JSON_OUT=$OUT/${TAG}_ot_times_bunny20.json MPT_LIB=$LIB/libmpt_hip_times.so timeout -k 10 300 python3 tools/gpu_ot_times.py bunny20.xml 64 > $OUT/${TAG}_ot_times_bunny20.txt 2>&1 || exit 1
+BVH=3 JSON_OUT=$OUT/${TAG}_ot_times_bunny20.json MPT_LIB=$LIB/libmpt_hip_times.so timeout -k 10 300 python3 tools/gpu_ot_times.py bunny20.xml 64 > $OUT/${TAG}_ot_times_bunny20.txt 2>&1 || exit 1
 MPT_LIB=$LIB/libmpt_hip_clock.so timeout -k 10 300 python3 tools/gpu_clock.py > $OUT/${TAG}_inkernel_clock.txt 2>&1 || exit 1
 timeout -k 10 600 python3 tools/gpu_devbuild.py 64 > $OUT/${TAG}_devbuild.txt 2>&1 || exit 1
 timeout -k 10 600 python3 tools/gpu_shard_time.py > $OUT/${TAG}_shard_time.txt 2>&1 || exit 1
