@@ -1,8 +1,9 @@
 """After `gpurun -- 'bash tools/profiles_round.sh r03'`: turns gpurun_out/r03_* into the tracked files under profiles/.
-usage: python tools/profiles_collect.py [tag]"""
+usage: python tools/profiles_collect.py [tag] [--pmc-only]"""
 import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r03"
+pmc_only = "--pmc-only" in sys.argv   # (on the GPU box, between the counter passes and bench.py: the line can then name its profile)
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 notes = {"wl": ("pmc_wavelocal", "scene.xml 1920x1080, 256 spp, depth 8, device-built binned-SAH tree (leaves <= 8): the default bench.py step."),
          "ot": ("pmc_ordered", "scene.xml 1920x1080, 256 spp, depth 8, reference tree, MPT_PIPE_ORDERED."),
@@ -11,6 +12,8 @@ notes = {"wl": ("pmc_wavelocal", "scene.xml 1920x1080, 256 spp, depth 8, device-
 for k, (name, note) in notes.items():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_finalize.py"), tag + k, os.path.join(P, "%s_%s.json" % (tag, name)), note],
                           stdout=subprocess.DEVNULL)
+if pmc_only:
+    sys.exit(0)
 mem = json.load(open(os.path.join(G, tag + "otb_mem.json")))
 mem["note"] = ("memory-pipe counters of ONE k_ordered launch on bunny x20 (64 spp; tools/pmc_mem.sh: texture addresser, vector L1, texture data, L2 requests; "
                "one rocprofv3 --pmc pass per set).  TCP_TOTAL_CACHE_ACCESSES / TCP_TA_TCP_STATE_READ = tag look-ups per wave load instruction.")

@@ -10,6 +10,7 @@ PIPE=3 bash tools/pmc_round.sh ${TAG}ot k_ordered > $OUT/${TAG}_pmc_ot.log 2>&1 
 SCENE=bunny20.xml BVH=3 SPP=64 PIPE=3 bash tools/pmc_round.sh ${TAG}otb k_ordered > $OUT/${TAG}_pmc_otb.log 2>&1 || exit 1
 SCENE=bunny20.xml BVH=3 SPP=64 PIPE=2 bash tools/pmc_round.sh ${TAG}wlb k_wavelocal > $OUT/${TAG}_pmc_wlb.log 2>&1 || exit 1
 SCENE=bunny20.xml BVH=3 SPP=64 PIPE=3 bash tools/pmc_mem.sh ${TAG}otb k_ordered > $OUT/${TAG}_mem_otb.log 2>&1 || exit 1
+python3 tools/profiles_collect.py $TAG --pmc-only || exit 1   # profiles/<tag>_pmc_*.json of THIS build, for the bench lines below
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/bench_trace
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -o b -- python3 $ROOT/bench.py --steps 8 --warmup 2 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err || exit 1
