@@ -72,10 +72,12 @@ def main():
     d = 8 if quick else 1
     sc, _ = load(os.path.join(ASSETS, "cornell.xml"), host.BVH_REFERENCE_SWEEP)
     measure("cfg0 cornell 256x256x16 d32 (GPU run of the CPU config)", sc, 256, 256, 16, 32, capi.BSDF_LAMBERT, CORNELL_CAM, 1)
-    measure("     cornell 1920x1080x256 d8", sc, 1920, 1080, 256 // d, 8, capi.BSDF_LAMBERT, CORNELL_CAM, 1)
+    for dev, tag in ((False, "reference tree"), (True, "device build")):
+        measure("     cornell 1920x1080x256 d8, %s" % tag, sc, 1920, 1080, 256 // d, 8, capi.BSDF_LAMBERT, CORNELL_CAM, 1, device_build=dev)
     sc, _ = load(os.path.join(ASSETS, "scene.xml"), host.BVH_REFERENCE_SWEEP)
-    measure("cfg1 scene.xml 1920x1080x256 d8", sc, 1920, 1080, 256 // d, 8, capi.BSDF_LAMBERT, None, 1)
-    measure("     scene.xml 1920x1080x256 d32", sc, 1920, 1080, 256 // d, 32, capi.BSDF_LAMBERT, None, 1)
+    for dev, tag in ((False, "reference tree"), (True, "device build")):
+        measure("cfg1 scene.xml 1920x1080x256 d8, %s" % tag, sc, 1920, 1080, 256 // d, 8, capi.BSDF_LAMBERT, None, 1, device_build=dev)
+        measure("     scene.xml 1920x1080x256 d32, %s" % tag, sc, 1920, 1080, 256 // d, 32, capi.BSDF_LAMBERT, None, 1, device_build=dev)
     trees = ((host.BVH_REFERENCE_SWEEP, "reference tree"), (host.BVH_BINNED_CENTROID, "binned-SAH tree"), (host.BVH_GPU_LBVH, "GPU tree through the host"),
              (DEVICE, "device build"))
     for mode, tag in trees:
