@@ -1528,12 +1528,13 @@ static int gpu_builder() {
 }
 
 // Primitives per leaf of the GPU builders (MPT_LBVH_LEAF = 1..8 overrides).  Scenes that MPT_PIPE_AUTO renders with the
-// reference-order kernel (fewer than MPT_AUTO_ORDERED_PRIMS primitives: tree and primitives live in LDS there) get leaves of
-// <= 8 — scene.xml: 19.3 ms per 256 spp against 20.8 with leaves of 2 and 21.3 on the reference's own tree; the closest-first
-// kernel tests every primitive of a leaf it enters and wants them small (bunny x20: 12.5 Grays/s with 4, 13.2 with 2).
+// reference-order kernel (fewer than MPT_AUTO_ORDERED_PRIMS primitives: the tree and a prefix of the primitives live in LDS
+// there) get leaves of <= 6 — scene.xml, ms per 256 spp with 2 / 4 / 5 / 6 / 7 / 8: 20.8 / 19.3 / 19.2 / 18.6 / 18.9 / 19.1,
+// against 21.3 on the reference's own tree; the closest-first kernel tests every primitive of a leaf it enters and wants them
+// small (bunny x20: 12.5 Grays/s with 4, 13.2 with 2).
 static int gpu_leaf_max(uint64_t n_prims) {
     if (const char* lm = getenv("MPT_LBVH_LEAF")) return std::min(std::max(atoi(lm), 1), (int)MPT_LBVH_LEAF_MAX);
-    return n_prims < MPT_AUTO_ORDERED_PRIMS ? 8 : 2;
+    return n_prims < MPT_AUTO_ORDERED_PRIMS ? 6 : 2;
 }
 
 // ---- build -> render without the host (mpt_devbuild.h) -------------------------------------------------------------------------

@@ -110,6 +110,9 @@ struct SahTask {
 #ifndef MPT_SAH_SAMPLE
 #define MPT_SAH_SAMPLE 256u  // a wave's task bins an evenly spaced sample of about this many of its items
 #endif
+#ifndef MPT_SAH_SMALL_EXACT
+#define MPT_SAH_SMALL_EXACT 1   // nodes of <= MPT_SAH_SMALL items: sweep over the sorted box centres instead of 16 bins
+#endif
 #ifndef MPT_SAH_SMALL
 #define MPT_SAH_SMALL 8u     // tasks of at most this many items (8 or 16) are FINISHED, sub-tree and all, by as many lanes (k_sah_small)
 #endif
@@ -662,7 +665,9 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
             s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
             sah_attach(st, s_child, parent, side, TOP + (int)k);
         }
-        // bins of this lane's item; the plane behind each of them, priced over the range
+        // the plane behind this lane's item on every axis, priced over the range.  MPT_SAH_SMALL_EXACT (default): "behind" is the
+        // order of the box centres themselves (ties by lane) — a full sweep, every partition an axis can make; 0: the 16 bins of
+        // the larger nodes (the host builder's choices exactly)
         float inv[3];
         int q3[3];
         for (int a = 0; a < 3; ++a) {
@@ -672,6 +677,7 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
             q3[a] = q < 0 ? 0 : (q > 15 ? 15 : q);
         }
         const int qpack = q3[0] | (q3[1] << 4) | (q3[2] << 8);
+        (void)qpack;
         float L[3][6], R[3][6];
         int cL[3] = {0, 0, 0}, cR[3] = {0, 0, 0};
         for (int a = 0; a < 3; ++a)
@@ -683,7 +689,13 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
             const int cnt = __shfl(__float_as_int(h.w), src), qo = __shfl(qpack, src);
             if (same)
                 for (int a = 0; a < 3; ++a) {
+#if MPT_SAH_SMALL_EXACT
+                    const float co = 0.5f * (b6[a] + b6[3 + a]);
+                    const bool left = co < c3[a] || (co == c3[a] && i <= gl);
+                    (void)qo;
+#else
                     const bool left = ((qo >> (4 * a)) & 15) <= q3[a];
+#endif
                     for (int c = 0; c < 3; ++c) {
                         if (left) L[a][c] = fminf(L[a][c], b6[c]), L[a][3 + c] = fmaxf(L[a][3 + c], b6[3 + c]);
                         else R[a][c] = fminf(R[a][c], b6[c]), R[a][3 + c] = fmaxf(R[a][3 + c], b6[3 + c]);
@@ -698,7 +710,11 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
             if (!live || inv[a] == 0.0f || cL[a] == 0 || cR[a] == 0) continue;
             const float c = half_area4(make_float4(L[a][0], L[a][1], L[a][2], 0), make_float4(L[a][3], L[a][4], L[a][5], 0)) * (float)cL[a] +
                             half_area4(make_float4(R[a][0], R[a][1], R[a][2], 0), make_float4(R[a][3], R[a][4], R[a][5], 0)) * (float)cR[a];
+#if MPT_SAH_SMALL_EXACT
+            const int id = a * 16 + (int)gl;
+#else
             const int id = a * 15 + q3[a];
+#endif
             if (c < cost || (c == cost && id < cand)) cost = c, cand = id;
         }
         float best = INFINITY;
@@ -711,8 +727,18 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
             if (same && (c < best || (c == best && id < pick))) best = c, pick = id;
         }
         bool left;
+#if MPT_SAH_SMALL_EXACT
+        {
+            const int pa = pick == 0x7FFFFFFF ? 0 : pick / 16, pl = pick == 0x7FFFFFFF ? 0 : pick % 16, src = (int)gbase + pl;
+            const float p0 = __shfl(c3[0], src), p1 = __shfl(c3[1], src), p2 = __shfl(c3[2], src);
+            const float cp = pa == 0 ? p0 : pa == 1 ? p1 : p2, cm = pa == 0 ? c3[0] : pa == 1 ? c3[1] : c3[2];
+            left = cm < cp || (cm == cp && (int)gl <= pl);
+        }
+        if (!(best < INFINITY)) left = gl - rb < m / 2u;   // no plane separates the box centres: halves
+#else
         if (best < INFINITY) left = q3[pick / 15] <= pick % 15;
         else left = gl - rb < m / 2u;   // no plane separates the box centres: halves
+#endif
         if (m == 2u) left = gl == rb;   // (two items: nothing to choose)
         // the partition, stable on both sides
         const unsigned long long seg = (re - rb >= 64u ? ~0ull : ((1ull << (re - rb)) - 1ull)) << (gbase + rb);

@@ -30,7 +30,7 @@ def _check_tree(bvh, idx, prims):
         depth_max = max(depth_max, depth[n])
         if cnt[n] > 0:
             leaves += 1
-            assert cnt[n] <= (8 if P < 8192 else 2) and 0 <= lf[n] and lf[n] + cnt[n] <= P   # (leaf size: mpt_hip.hip gpu_leaf_max)
+            assert cnt[n] <= (6 if P < 8192 else 2) and 0 <= lf[n] and lf[n] + cnt[n] <= P   # (leaf size: mpt_hip.hip gpu_leaf_max)
             covered[lf[n]:lf[n] + cnt[n]] += 1
             for k in range(cnt[n]):                                # the leaf box contains its primitives' boxes
                 p = prims[idx[lf[n] + k]]
@@ -98,7 +98,7 @@ def test_gpu_build_small_inputs_and_determinism(gpu_ctx, builder, monkeypatch):
         bvh2, idx2, _ = gpu_ctx.build_bvh(prims)
         np.testing.assert_array_equal(bvh.view(np.uint32), bvh2.view(np.uint32))
         np.testing.assert_array_equal(idx, idx2)
-        assert (n <= 8) == (bvh.shape[0] == 1)                       # scenes this small get leaves of <= 8 primitives (2 from 8192 on)
+        assert (n <= 6) == (bvh.shape[0] == 1)                       # scenes this small get leaves of <= 6 primitives (2 from 8192 on)
 
 
 @pytest.mark.parametrize("builder", ["sah", "sah+refit", "sah+sah", "ploc", "lbvh"])
