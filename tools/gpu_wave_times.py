@@ -13,7 +13,8 @@ flags = capi.FLAG_COUNT_WORK if os.environ.get("COUNT") else 0
 for rep in range(2):
     if rep: L.mpt_debug_reset()
     ctx.clear_sum(); ctx.reset_stats()
-    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2, flags=flags)
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2, flags=flags,
+               shard_rank=0, shard_count=int(os.environ.get("SHARDS", "1")))   # SHARDS=8: one GPU's tile shard of an 8-GPU render
 st = ctx.stats()
 n = int(os.environ.get("WAVES", "6144"))
 raw = np.zeros(2 * n * 8 + 128, np.uint64)
