@@ -555,9 +555,10 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     SahState* d_st;
     int2* s_child;
     float4 *s_lo, *s_hi;
-    // (the builder's own tree serves when no sphere sits on the always list: the spheres' boxes — a ground sphere of radius
-    //  1e4 — shaped its top splits, and the own tree leaves them out; MPT_OWN_TREE = refit | sah forces either way)
-    bool refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && (n_spheres_hint == 0 || !use_always);
+    // (the builder's own tree serves when its SAH nodes hold no sphere — the builder hangs up to 16 spheres under the root,
+    //  mpt_lbvh.h — or when no always list is used; with spheres inside the SAH their boxes shape the top splits, which the own
+    //  tree leaves out: a second SAH over the leaves then.  MPT_OWN_TREE = refit | sah forces either way)
+    bool refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && (R.spheres_hoisted || n_spheres_hint == 0 || !use_always);
     if (const char* e = getenv("MPT_OWN_TREE")) refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && strcmp(e, "refit") == 0;
     if (refit) {
         int *eff, *arrived;

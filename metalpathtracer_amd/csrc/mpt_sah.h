@@ -135,6 +135,11 @@ __device__ __forceinline__ int f2o(float f) {  // order-preserving float -> int
     return i >= 0 ? i : i ^ 0x7FFFFFFF;
 }
 __device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+// (bits of the box's half area) << 32 | item index: the maximum over a node's items names the one with the largest box
+__device__ __forceinline__ unsigned long long sah_area_key(float4 l, float4 h, uint32_t i) {
+    const float a = half_area4(l, h);
+    return ((unsigned long long)(a > 0.0f && a < INFINITY ? __float_as_uint(a) : 0u) << 32) | i;
+}
 
 __global__ void k_sah_init(const uint32_t* count /* device word, or null */, uint32_t count_host, SahState* st, SahTask* tasks, SahTask* big_tasks,
                            SahTask* small_tasks) {
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
     // pass 1: the node's box and the bounds of the box centres
     float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
           ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    unsigned long long largest = 0ull;   // (bits of the area) << 32 | item: the item with the largest box (see the sample below)
     for (uint32_t i = b + lane; i < e; i += 64u) {
         const float4 l = in_lo[i], h = in_hi[i];
         const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
@@ -207,6 +213,12 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
             cl[a] = fminf(cl[a], c);
             ch[a] = fmaxf(ch[a], c);
         }
+        const unsigned long long key = sah_area_key(l, h, i);
+        largest = key > largest ? key : largest;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(largest, off);
+        largest = o > largest ? o : largest;
     }
     for (int off = 32; off > 0; off >>= 1)
         for (int a = 0; a < 3; ++a) {
@@ -234,8 +246,10 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
     }
     // (a node of more than 256 items is binned from an evenly spaced sample of ~256 of them: the 21 LDS atomics per item are
     //  what this pass costs, and 256 boxes choose among 45 planes as well as 100,000 do; box and partition stay exact)
+    // ... plus THE item with the largest box when the sample missed it: a ground sphere of radius 1e4 among 5000 triangles
+    // that no plane is priced against stays with half of them, and every ray walks through its box a level longer)
     const uint32_t step = m > MPT_SAH_SAMPLE ? m / MPT_SAH_SAMPLE : 1u;
-    for (uint32_t i = b + lane * step; i < e; i += 64u * step) {
+    auto bin_item = [&](uint32_t i) {
         const float4 l = in_lo[i], h = in_hi[i];
         const int cnt = __float_as_int(h.w);
         const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
@@ -248,7 +262,9 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
             atomicMax(&B[3], f2o(h.x)); atomicMax(&B[4], f2o(h.y)); atomicMax(&B[5], f2o(h.z));
             atomicAdd(&B[6], cnt);
         }
-    }
+    };
+    for (uint32_t i = b + lane * step; i < e; i += 64u * step) bin_item(i);
+    if (lane == 0 && step > 1u && ((uint32_t)largest - b) % step != 0u) bin_item((uint32_t)largest);
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     // pass 3: lane = (axis, split after bin s): cost = area(L) * count(L) + area(R) * count(R)
@@ -345,6 +361,7 @@ struct SahBig {
     int pick;         // axis * 15 + split, or -1: halves
     float cl[3], inv[3];
     int one[2];       // id of the first item on either side (THE item if it stays alone)
+    unsigned long long largest;   // sah_area_key of the item with the largest box
 };
 __device__ __forceinline__ uint32_t sah_chunks(const SahTask& t) { return (t.e - t.b + MPT_SAH_CHUNK - 1u) / MPT_SAH_CHUNK; }
 __global__ __launch_bounds__(1024) void k_big_prep(const SahTask* tasks, uint32_t n_big, SahBig* big, uint32_t* coff /* [n_big + 1] */) {
@@ -369,6 +386,7 @@ __global__ __launch_bounds__(1024) void k_big_prep(const SahTask* tasks, uint32_
             SahBig& B = big[t];
             for (int q = 0; q < 12; ++q) B.bounds[q] = q % 6 < 3 ? 0x7FFFFFFF : (int)0x80000000;
             B.one[0] = B.one[1] = 0;
+            B.largest = 0ull;
         }
         __syncthreads();
         if (tid == 1023u) s_run = before + x;
@@ -395,6 +413,7 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const floa
     const uint32_t b = task.b + (c - coff[t]) * MPT_SAH_CHUNK, e = b + MPT_SAH_CHUNK < task.e ? b + MPT_SAH_CHUNK : task.e;
     float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
           ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+    unsigned long long largest = 0ull;
     for (uint32_t i = b + tid; i < e; i += MPT_SAH_CHUNK_THREADS) {
         const float4 l = in_lo[i], h = in_hi[i];
         const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
@@ -405,6 +424,12 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const floa
             cl[a] = fminf(cl[a], cc);
             ch[a] = fmaxf(ch[a], cc);
         }
+        const unsigned long long key = sah_area_key(l, h, i);
+        largest = key > largest ? key : largest;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(largest, off);
+        largest = o > largest ? o : largest;
     }
     for (int off = 32; off > 0; off >>= 1)
         for (int a = 0; a < 3; ++a) {
@@ -414,8 +439,11 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const floa
             ch[a] = fmaxf(ch[a], __shfl_xor(ch[a], off));
         }
     __shared__ int s_b[12];
+    __shared__ unsigned long long s_largest;
     if (tid < 12u) s_b[tid] = tid % 6u < 3u ? 0x7FFFFFFF : (int)0x80000000;
+    if (tid == 0) s_largest = 0ull;
     __syncthreads();
+    if (lane == 0) atomicMax(&s_largest, largest);
     if (lane == 0)
         for (int a = 0; a < 3; ++a) {
             atomicMin(&s_b[a], f2o(nl[a]));
@@ -429,6 +457,7 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const floa
         if (tid % 6u < 3u) atomicMin(&B[tid], s_b[tid]);
         else atomicMax(&B[tid], s_b[tid]);
     }
+    if (tid == 12u) atomicMax(&big[t].largest, s_largest);
 }
 __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahBig* big, SahState* st,
                                                                   int2* s_child, float4* s_lo, float4* s_hi) {
@@ -457,8 +486,11 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
         s_hi[k] = make_float4(o2f(G.bounds[3]), o2f(G.bounds[4]), o2f(G.bounds[5]), 0.0f);
         sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
     }
-    const uint32_t step = m > MPT_SAH_SAMPLE_BIG ? m / MPT_SAH_SAMPLE_BIG : 1u;   // (binned from a sample of ~1024 items: see k_sah_level)
-    for (uint32_t i = b + tid * step; i < e; i += MPT_SAH_BIG_THREADS * step) {
+    // (binned from a sample of ~1024 items, plus the one with the largest box if the sample missed it: see k_sah_level)
+    // (up to 8192 items all are binned: a scene of 5000 primitives keeps the host builder's exact choices at its root, where two
+    //  unsampled spheres of radius 10 and 40 made the sample prefer another axis)
+    const uint32_t step = m > 8u * MPT_SAH_SAMPLE_BIG ? m / MPT_SAH_SAMPLE_BIG : 1u;
+    auto bin_item = [&](uint32_t i) {
         const float4 l = in_lo[i], h = in_hi[i];
         const int cnt = __float_as_int(h.w);
         const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
@@ -471,7 +503,9 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
             atomicMax(&B[3], f2o(h.x)); atomicMax(&B[4], f2o(h.y)); atomicMax(&B[5], f2o(h.z));
             atomicAdd(&B[6], cnt);
         }
-    }
+    };
+    for (uint32_t i = b + tid * step; i < e; i += MPT_SAH_BIG_THREADS * step) bin_item(i);
+    if (tid == 0 && step > 1u && ((uint32_t)G.largest - b) % step != 0u) bin_item((uint32_t)G.largest);
     __syncthreads();
     if (tid < 48u) {
         float cost = INFINITY;

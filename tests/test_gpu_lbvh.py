@@ -287,3 +287,58 @@ def test_build_and_upload_survives_degenerate_input(gpu_ctx):
             to, po, no, fo = ob.first_hit(o[i], d[i], buffers)
             assert po == p0[i] and (po < 0 or np.float32(to) == t0[i]), (variant, i)
         # (how much is hit is the reference's business: a NaN vertex poisons the boxes above it, for the oracle and the device alike)
+
+
+def _sah_cost(bvh, idx, prims):
+    """SAH cost of the part of a tree (reference buffer format) that holds triangles only: sum over those nodes of box area
+    over the area of the triangles' bounding box, times 1 for an inner node and the primitive count for a leaf — the quantity
+    the builders minimise.  (Nodes with a sphere below them are left out: scene.xml's ground sphere of radius 1e4 would be
+    all there is to see otherwise.)"""
+    raw = np.ascontiguousarray(np.asarray(bvh, np.float32).reshape(-1, 8))
+    lf, cnt = raw[:, 3].copy().view(np.int32), raw[:, 7].copy().view(np.int32)
+    P = np.asarray(prims, np.float32).reshape(-1, 12)
+    idx = np.asarray(idx)
+    tri = P[:, 3] == 1.0
+    v = np.stack([P[tri, 0:3], P[tri, 4:7], P[tri, 8:11]], 1)
+    e = v.max((0, 1)).astype(np.float64) - v.min((0, 1)).astype(np.float64)
+    norm = e[0] * e[1] + e[1] * e[2] + e[2] * e[0]
+    ext = np.maximum(raw[:, 4:7].astype(np.float64) - raw[:, 0:3].astype(np.float64), 0.0)
+    area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
+    has_sphere = np.zeros(len(raw), bool)
+    order, stack = [], [0]
+    while stack:
+        n = stack.pop()
+        order.append(n)
+        if cnt[n] <= 0:
+            stack += [int(lf[n]), int(-cnt[n])]
+    for n in reversed(order):
+        if cnt[n] > 0:
+            has_sphere[n] = not tri[idx[lf[n]:lf[n] + cnt[n]]].all()
+        else:
+            has_sphere[n] = has_sphere[lf[n]] or has_sphere[-cnt[n]]
+    w = np.where(cnt > 0, cnt, 1).astype(np.float64)
+    keep = ~has_sphere
+    return float((area[keep] * w[keep]).sum() / norm)
+
+
+@pytest.mark.parametrize("name", ["bunny20.xml", "scene.xml"])
+def test_device_sah_tree_is_as_good_as_the_host_binned_builders(gpu_ctx, name, monkeypatch):
+    """The device builder runs the host binned builder's algorithm (over the triangles; the spheres hang under its root): the SAH
+    cost of the triangle part of its tree must match the host's within 3 %, and beat the clustering builders', at the same
+    leaf size."""
+    from metalpathtracer_amd import host
+    monkeypatch.setenv("MPT_LBVH_LEAF", "2")
+    monkeypatch.setenv("MPT_BINNED_LEAF", "2")
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(scene_path(name), sc)
+    assert st == 0, log
+    sc.buildBVH(host.BVH_BINNED_CENTROID)
+    b = sc.buffers()
+    ref = _sah_cost(b[0], b[3], b[1])
+    cost = {}
+    for builder in ("sah", "ploc", "lbvh"):
+        monkeypatch.setenv("MPT_GPU_BUILD", builder)
+        tree, prims, _, idx = host.make_ready(gpu_ctx, sc, host.BVH_DEVICE)
+        cost[builder] = _sah_cost(tree, idx, prims)
+    assert cost["sah"] < 1.03 * ref, (cost, ref)
+    assert cost["sah"] < cost["ploc"] and cost["sah"] < cost["lbvh"], (cost, ref)
