@@ -49,7 +49,11 @@ struct BuildContext {
     std::vector<float> key[3];       // data0[axis]
     std::vector<float3> cen;         // centroid of the bounds (binned builder)
 
-    BuildContext(const std::vector<Primitive>& p, std::vector<size_t>& o, std::vector<BVHNode>& n)
+    // pad_flat (the binned builder; never the reference's own): no primitive box thinner than 2^-16 of its size / position.
+    // The reference's slab test never enters a box of zero thickness (PathTracing.h:68 rejects tMax <= tMin), and small
+    // leaves pair up the two coplanar halves of an axis-aligned quad — a Cornell-box wall — where the reference's leaves of
+    // eight mix orientations: the wall would be invisible.  (The GPU builders: the same rule, mpt_lbvh.h k_boxes.)
+    BuildContext(const std::vector<Primitive>& p, std::vector<size_t>& o, std::vector<BVHNode>& n, bool pad_flat)
         : prims(p), order(o), nodes(n) {
         const size_t count = p.size();
         lo.resize(count);
@@ -65,6 +69,19 @@ struct BuildContext {
             } else {
                 lo[i] = mpt::min3(q.data0, mpt::min3(q.data1, q.data2));
                 hi[i] = mpt::max3(q.data0, mpt::max3(q.data1, q.data2));
+            }
+            if (pad_flat) {
+                float l3[3] = {lo[i].x, lo[i].y, lo[i].z}, h3[3] = {hi[i].x, hi[i].y, hi[i].z};
+                const float ext = std::max(h3[0] - l3[0], std::max(h3[1] - l3[1], h3[2] - l3[2]));
+                for (int a = 0; a < 3; ++a) {
+                    const float pad = std::max(std::max(std::fabs(l3[a]), std::fabs(h3[a])), ext) * 1.52587890625e-05f;
+                    if (h3[a] - l3[a] < pad) {
+                        l3[a] -= pad;
+                        h3[a] += pad;
+                    }
+                }
+                lo[i] = float3(l3[0], l3[1], l3[2]);
+                hi[i] = float3(h3[0], h3[1], h3[2]);
             }
             cen[i] = (lo[i] + hi[i]) * 0.5f;
             key[0][i] = q.data0.x;
@@ -321,7 +338,7 @@ void Scene::buildBVH(BuildMode mode) {
         buildOnGpu();
         return;
     }
-    BuildContext ctx(primitives_, primitiveIndices_, nodes_);
+    BuildContext ctx(primitives_, primitiveIndices_, nodes_, mode != BuildMode::ReferenceSweep);
     // levels of forking: 2^forks concurrent subtree tasks at most (MPT_BUILD_THREADS=1 builds sequentially)
     unsigned threads = std::thread::hardware_concurrency();
     if (const char* e = std::getenv("MPT_BUILD_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(e)));

@@ -47,6 +47,20 @@ __global__ void k_boxes(const float4* prims, uint32_t n, float4* blo, float4* bh
             lo[0] = fminf(p0.x, fminf(p1.x, p2.x)); lo[1] = fminf(p0.y, fminf(p1.y, p2.y)); lo[2] = fminf(p0.z, fminf(p1.z, p2.z));
             hi[0] = fmaxf(p0.x, fmaxf(p1.x, p2.x)); hi[1] = fmaxf(p0.y, fmaxf(p1.y, p2.y)); hi[2] = fmaxf(p0.z, fmaxf(p1.z, p2.z));
         }
+        // The reference's slab test never enters a box of zero thickness (PathTracing.h:68 rejects tMax <= tMin): a leaf of
+        // coplanar, axis-aligned triangles — the two halves of a Cornell-box wall, which these builders' small leaves pair
+        // up where the reference's leaves of eight mix orientations — would be invisible.  So no primitive box is thinner
+        // than 2^-16 of its own size / position (host binned builder: the same rule, Scene.cpp).
+        {
+            const float ext = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
+            for (int a = 0; a < 3; ++a) {
+                const float pad = fmaxf(fmaxf(fabsf(lo[a]), fabsf(hi[a])), ext) * 1.52587890625e-05f;
+                if (hi[a] - lo[a] < pad) {
+                    lo[a] -= pad;
+                    hi[a] += pad;
+                }
+            }
+        }
         blo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         bhi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
         for (int a = 0; a < 3; ++a) c[a] = 0.5f * lo[a] + 0.5f * hi[a];

@@ -342,3 +342,40 @@ def test_device_sah_tree_is_as_good_as_the_host_binned_builders(gpu_ctx, name, m
         cost[builder] = _sah_cost(tree, idx, prims)
     assert cost["sah"] < 1.03 * ref, (cost, ref)
     assert cost["sah"] < cost["ploc"] and cost["sah"] < cost["lbvh"], (cost, ref)
+
+
+def test_flat_walls_stay_visible_on_the_products_trees(gpu_ctx, monkeypatch):
+    """The reference's slab test never enters a box of zero thickness (PathTracing.h:68), so a leaf that holds only the two
+    coplanar halves of an axis-aligned Cornell-box wall would make the wall invisible.  The reference's own leaves (<= 8,
+    mixed orientations) are not flat in cornell.xml; the product's builders make small leaves and therefore give every
+    primitive box a thickness: their trees must render what the reference's tree renders, up to the rays whose answer depends
+    on the visit order."""
+    from conftest import CORNELL_CAM, pixel_l2
+    from metalpathtracer_amd import capi, host
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(scene_path("cornell.xml"), sc)
+    assert st == 0, log
+    W, H, spp = 192, 192, 8
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=CORNELL_CAM))
+
+    def render(bvh):
+        host.make_ready(gpu_ctx, sc, bvh)
+        gpu_ctx.clear_sum()
+        gpu_ctx.reset_stats()
+        gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=spp, seed=(3, 1))
+        return gpu_ctx.read_sum() / spp, gpu_ctx.stats()["rays"]
+
+    ref, rays = render(host.BVH_REFERENCE_SWEEP)
+    assert rays > 2.3 * W * H * spp                                # the box is closed on five sides: paths bounce
+    cases = [("binned", host.BVH_BINNED_CENTROID, None), ("gpu through the host", host.BVH_GPU_LBVH, "sah")]
+    cases += [("device " + b, host.BVH_DEVICE, b) for b in ("sah", "ploc", "lbvh")]
+    for leaf in ("2", "6"):
+        monkeypatch.setenv("MPT_LBVH_LEAF", leaf)
+        monkeypatch.setenv("MPT_BINNED_LEAF", leaf)
+        for tag, bvh, builder in cases:
+            if builder:
+                monkeypatch.setenv("MPT_GPU_BUILD", builder)
+            img, r = render(bvh)
+            assert abs(r - rays) <= 1e-3 * rays, (tag, leaf, r, rays)
+            assert pixel_l2(img, ref) < 1e-3, (tag, leaf)
