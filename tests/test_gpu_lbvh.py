@@ -379,3 +379,29 @@ def test_flat_walls_stay_visible_on_the_products_trees(gpu_ctx, monkeypatch):
             img, r = render(bvh)
             assert abs(r - rays) <= 1e-3 * rays, (tag, leaf, r, rays)
             assert pixel_l2(img, ref) < 1e-3, (tag, leaf)
+
+
+@pytest.mark.parametrize("name,bsdf,W,H,spp", [("scene.xml", 0, 240, 135, 4), ("glass.xml", 1, 240, 135, 4), ("bunny20.xml", 0, 160, 90, 2)])
+def test_throughput_trees_render_the_image_of_the_reference_tree(gpu_ctx, name, bsdf, W, H, spp):
+    """`--bvh auto` / bench.py build the tree on the device; the drop-in default is the reference's own builder.  Both must show
+    the same picture: equal up to the rays whose answer depends on the visit order (ties between primitives), i.e. nearly
+    the same ray count and a per-pixel L2 far below the north-star tolerance."""
+    from conftest import pixel_l2
+    from metalpathtracer_amd import capi, host
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(scene_path(name), sc)
+    assert st == 0, log
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
+    out = {}
+    for bvh in (host.BVH_REFERENCE_SWEEP, host.BVH_BINNED_CENTROID, host.BVH_DEVICE):
+        host.make_ready(gpu_ctx, sc, bvh)
+        gpu_ctx.clear_sum()
+        gpu_ctx.reset_stats()
+        gpu_ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=8, sample_count=spp, seed=(9, 4))
+        out[bvh] = (gpu_ctx.read_sum() / spp, gpu_ctx.stats()["rays"])
+    ref, rays = out[host.BVH_REFERENCE_SWEEP]
+    for bvh in (host.BVH_BINNED_CENTROID, host.BVH_DEVICE):
+        img, r = out[bvh]
+        assert abs(r - rays) <= 1e-4 * rays + 4, (bvh, r, rays)
+        assert pixel_l2(img, ref) < 1e-4, bvh
