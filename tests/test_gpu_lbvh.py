@@ -405,3 +405,47 @@ def test_throughput_trees_render_the_image_of_the_reference_tree(gpu_ctx, name, 
         img, r = out[bvh]
         assert abs(r - rays) <= 1e-4 * rays + 4, (bvh, r, rays)
         assert pixel_l2(img, ref) < 1e-4, bvh
+
+
+@pytest.mark.parametrize("builder", ["sah", "ploc"])
+def test_builders_at_the_kernels_size_boundaries(gpu_ctx, builder, monkeypatch):
+    """Primitive counts on both sides of every switch inside the builders — the lane-per-item kernel (<= 8 items), the
+    workgroup-chunk kernels (>= 2048), the full-binning limit and the leaf-size / pipeline switch (8192) — with 0, 1, 16 and 17
+    spheres (hoisted under the root up to 16): well-formed tree, the same arrays on a second build, and both walks agree with
+    the oracle's closest hit on the downloaded tree."""
+    monkeypatch.setenv("MPT_GPU_BUILD", builder)
+    rng = np.random.default_rng(23)
+    cases = [(5, 0), (8, 1), (9, 0), (17, 16), (33, 17), (257, 1), (2047, 0), (2048, 3), (2049, 16), (4100, 1), (8191, 0), (8192, 2), (8300, 17)]
+    for n, n_sph in cases:
+        prims = np.zeros((n, 12), np.float32)
+        prims[:, 3] = 1.0
+        v0 = rng.uniform(-20, 20, (n, 3))
+        prims[:, 0:3], prims[:, 4:7], prims[:, 8:11] = v0, v0 + rng.uniform(-1, 1, (n, 3)), v0 + rng.uniform(-1, 1, (n, 3))
+        prims[:n_sph, 3], prims[:n_sph, 4:12] = 0.0, 0.0
+        prims[:n_sph, 4] = rng.uniform(0.5, 3.0, n_sph)
+        if n_sph:
+            prims[0, 0:3], prims[0, 4] = (0.0, -1000.0, 0.0), 980.0     # a ground sphere far larger than the rest
+        mats = np.zeros((n, 8), np.float32)
+        mats[:, 0:3] = 0.5
+        gpu_ctx.build_and_upload(prims, mats)
+        bvh, idx = gpu_ctx.download_bvh()
+        _check_tree(bvh.reshape(-1, 8), idx, prims)
+        gpu_ctx.build_and_upload(prims, mats)
+        bvh2, idx2 = gpu_ctx.download_bvh()
+        np.testing.assert_array_equal(bvh.view(np.uint32), bvh2.view(np.uint32))
+        np.testing.assert_array_equal(idx, idx2)
+        m = 2048
+        o = (rng.normal(size=(m, 3)) * 25).astype(np.float32)
+        d = (rng.normal(size=(m, 3)) * 10 - o).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        t0, p0, n0, f0 = gpu_ctx.trace_rays(o, d)
+        buffers = (bvh, prims.reshape(-1, 3, 4), mats.reshape(-1, 2, 4), idx)
+        for i in range(0, m, 64):
+            to, po, no, fo = ob.first_hit(o[i], d[i], buffers)
+            assert po == p0[i] and (po < 0 or np.float32(to) == t0[i]), (n, n_sph, i)
+        if n_sph <= 16:
+            assert gpu_ctx.accel_info()["ordered_ok"] == 1
+            t1, p1, n1, f1, fl = gpu_ctx.trace_rays_ordered(o, d)
+            np.testing.assert_array_equal(t0.view(np.uint32), t1.view(np.uint32))
+            np.testing.assert_array_equal(p0, p1)
+        assert n < 257 or (p0 >= 0).sum() > m // 50, (n, n_sph)
