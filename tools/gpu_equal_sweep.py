@@ -12,13 +12,14 @@ scenes = {}
 total = 0; bad = 0; t0 = time.time()
 for case in range(cases):
     name = str(rng.choice(["scene.xml", "glass.xml", "bunny20.xml", "cornell.xml"]))
-    mode = int(rng.choice([host.BVH_REFERENCE_SWEEP, host.BVH_BINNED_CENTROID, host.BVH_GPU_LBVH]))
-    key = (name, mode)
+    mode = int(rng.choice([host.BVH_REFERENCE_SWEEP, host.BVH_BINNED_CENTROID, host.BVH_GPU_LBVH, host.BVH_DEVICE, host.BVH_DEVICE]))
+    os.environ["MPT_LBVH_LEAF"] = str(rng.choice(["2", "2", "4", "6"]))     # (device builds: leaf sizes of both kinds of scene)
+    key = name
     if key not in scenes:
         sc = host.Scene(); st, log = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", name), sc); assert st == 0, log
-        sc.buildBVH(mode); scenes[key] = (sc, sc.buffers())
-    sc, buf = scenes[key]
-    ctx.upload_scene(*buf)
+        scenes[key] = sc
+    sc = scenes[key]
+    host.make_ready(ctx, sc, mode)
     if ctx.accel_info()["ordered_ok"] != 1:
         continue
     W, H = [(1920, 1080), (1280, 720), (2560, 1440), (1000, 1000)][int(rng.integers(0, 4))]
