@@ -100,7 +100,7 @@ void Renderer::updateVisibleScene() {
     const Scene::BuildMode mode = want == BUILD_BINNED ? Scene::BuildMode::BinnedCentroid
                                   : want == BUILD_GPU  ? Scene::BuildMode::GpuLbvh
                                                        : Scene::BuildMode::ReferenceSweep;
-    std::printf("BVH builder: %s\n", want == BUILD_BINNED ? "binned SAH (host)" : want == BUILD_GPU ? "linear BVH (device, build -> render without the host)" : "reference sweep SAH");
+    std::printf("BVH builder: %s\n", want == BUILD_BINNED ? "binned SAH (host)" : want == BUILD_GPU ? "binned SAH on the device (build -> render without the host)" : "reference sweep SAH");
     deviceBuild_ = want == BUILD_GPU;
     if (deviceBuild_) {   // mpt_build_and_upload in buildBuffers(): the tree never exists on the host
         scene_->sortPrimitives();
