@@ -159,12 +159,13 @@ def extra_workloads(ctx, capi, host, depth):
             out.append({"workload": name, "error": log[-200:]})
             continue
         t0 = time.perf_counter()
-        sc.buildBVH(host.BVH_REFERENCE_SWEEP)
         if builder == "device":                      # what the Renderer does for a scene of this size: build -> render on the device
+            sc.sortPrimitives()
             prims, mats = sc.packed_primitives()
             t0 = time.perf_counter()
             ctx.build_and_upload(prims, mats)
         else:
+            sc.buildBVH(host.BVH_REFERENCE_SWEEP)
             ctx.upload_scene(*sc.buffers())
         setup_ms = (time.perf_counter() - t0) * 1e3
         W, H, spp = 1920, 1080, 256

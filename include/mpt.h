@@ -212,7 +212,9 @@ int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]);
 /* BVH construction on the GPU — stands where the reference has Scene::buildBVH / buildBVHRecursive (R/Scene/Scene.h:71-93,
  * 195-317: sequential full-sweep SAH, 8.2 s for 1 M primitives): a top-down binned SAH over the primitives, built level by
  * level on the device (16 bins over the box centres, cost = area * primitives: the tree of the host's binned builder), with
- * leaves of <= 2 primitives (MPT_LBVH_LEAF: 1..8), written in the REFERENCE's buffer format so that
+ * leaves of <= mpt_gpu_leaf_max(n_prims) primitives — 6 for scenes below MPT_AUTO_ORDERED_PRIMS primitives (the ones the
+ * reference-order kernel renders: tree and hot primitives sit in LDS there), 2 from there on (the closest-first kernel tests
+ * every primitive of a leaf it enters); MPT_LBVH_LEAF = 1..8 overrides — written in the REFERENCE's buffer format so that
  * mpt_upload_scene (and the reference's shader, and the oracle) can consume it: bvh_out = 2 float4 per node as
  * Scene::createBVHBuffer returns them (root = node 0), prim_idx_out = Scene::createPrimitiveIndexBuffer.  The same input
  * gives the same arrays on every call.  MPT_GPU_BUILD = ploc | lbvh selects the two earlier builders instead (63-bit
@@ -233,6 +235,15 @@ int mpt_build_bvh(mpt_ctx* ctx, const float* prims, uint64_t n_prims, float* bvh
  * mpt_build_bvh does): what the reference's shader — and the oracle — would walk to produce the same image.                 */
 int mpt_build_and_upload(mpt_ctx* ctx, const float* prims, const float* mats, uint64_t n_prims, double* device_ms_out);
 int mpt_download_bvh(mpt_ctx* ctx, float* bvh_out, uint64_t bvh_capacity_nodes, uint64_t* n_nodes_out, int32_t* prim_idx_out);
+
+/* The leaf limit the GPU builders (mpt_build_bvh, mpt_build_and_upload) use for a scene of n_prims primitives: 6 below
+ * MPT_AUTO_ORDERED_PRIMS, 2 from there on, or what MPT_LBVH_LEAF says.  A pure function (no context).                      */
+int mpt_gpu_leaf_max(uint64_t n_prims);
+/* What the last scene call left on the device: out[0] = primitives of the tree mpt_download_bvh would return (0 when the scene
+ * came through mpt_upload_scene: MPT_ERR_NOT_READY there), [1] nodes of that tree, [2] the leaf limit it was built with,
+ * [3] MPT_AUTO_ORDERED_PRIMS (the scene size from which MPT_PIPE_AUTO means the closest-first pipeline), [4] primitives of the
+ * uploaded scene, [5] threaded reference-order nodes, [6] de-duplicated materials, [7] 0.                                   */
+int mpt_build_info(mpt_ctx* ctx, uint64_t out[8]);
 
 /* ---- multi-GPU: tile shards + ONE RCCL reduce of the HDR sum over xGMI ---------------------------------
  * The reference is single-GPU (it presents straight to the drawable, R/Renderer/Renderer.cpp:303-307); this is the

@@ -39,6 +39,9 @@ int mpt_scene_load_xml(mpt_scene* s, const char* xml_path, const char* asset_roo
 int mpt_scene_add_primitive(mpt_scene* s, int type, const float d0[3], const float d1[3], const float d2[3],
                             const float mat[8]);
 int mpt_scene_build_bvh(mpt_scene* s, int mode);
+/* Scene::sortPrimitives: spheres before triangles, stable — the first thing Scene::buildBVH does (R/Scene/Scene.h:72-75),
+ * and all that mpt_build_and_upload needs of it (primitive ids are the positions after this sort).  Drops a host tree. */
+int mpt_scene_sort_primitives(mpt_scene* s);
 int mpt_scene_counts(const mpt_scene* s, uint64_t* prims, uint64_t* triangles, uint64_t* nodes, int32_t* depth);
 /* copies the four flat buffers: bvh 8 floats/node, prims 12 floats/prim, mats 8 floats/prim,
  * prim_idx 1 int/prim; any pointer may be NULL to skip */

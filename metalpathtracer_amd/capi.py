@@ -27,7 +27,7 @@ SYMBOLS = (
     "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
     "mpt_read_frame", "mpt_read_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
     "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
-    "mpt_build_bvh", "mpt_build_and_upload", "mpt_download_bvh", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
+    "mpt_build_bvh", "mpt_build_and_upload", "mpt_download_bvh", "mpt_gpu_leaf_max", "mpt_build_info", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
     "mpt_comm_last_error",
 )
 
@@ -148,6 +148,8 @@ def load():
     L.mpt_build_bvh.argtypes = [vp, fp, C.c_uint64, fp, C.c_uint64, C.POINTER(C.c_uint64), ip, C.POINTER(C.c_double)]
     L.mpt_build_and_upload.argtypes = [vp, fp, fp, C.c_uint64, C.POINTER(C.c_double)]
     L.mpt_download_bvh.argtypes = [vp, fp, C.c_uint64, C.POINTER(C.c_uint64), ip]
+    L.mpt_gpu_leaf_max.argtypes = [C.c_uint64]
+    L.mpt_build_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.mpt_comm_unique_id.argtypes = [vp]
     L.mpt_comm_create_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
     L.mpt_comm_create_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
@@ -172,6 +174,11 @@ def _ip(a):
 
 def _up(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def gpu_leaf_max(n_prims):
+    """mpt_gpu_leaf_max: the leaf limit of the GPU builders for a scene of n_prims primitives (6 below 8192, 2 from there on)."""
+    return int(load().mpt_gpu_leaf_max(int(n_prims)))
 
 
 class Comm:
@@ -368,17 +375,25 @@ class Context:
         assert prims.shape[0] == mats.shape[0]
         ms = C.c_double()
         self._chk(self.L.mpt_build_and_upload(self.h, _fp(prims), _fp(mats), prims.shape[0], C.byref(ms)), "mpt_build_and_upload")
-        self._n_built = prims.shape[0]
         return ms.value
 
+    def build_info(self):
+        """mpt_build_info: what the last scene call left on the device (sizes come from the C API, not from this object)."""
+        out = (C.c_uint64 * 8)()
+        self._chk(self.L.mpt_build_info(self.h, out), "mpt_build_info")
+        keys = ("built_prims", "built_nodes", "built_leaf_max", "auto_ordered_prims", "prims", "threaded_nodes", "materials")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def download_bvh(self):
-        """The tree of the last build_and_upload in the reference's buffer format: (bvh [N, 2, 4] f32, prim_idx [P] i32)."""
-        n = self._n_built
-        bvh = np.zeros((2 * n - 1, 2, 4), np.float32)
-        idx = np.zeros(n, np.int32)
+        """The tree of the last build_and_upload in the reference's buffer format: (bvh [N, 2, 4] f32, prim_idx [P] i32).
+        MPT_ERR_NOT_READY when the scene on the device did not come from build_and_upload."""
+        info = self.build_info()
+        n, nodes = info["built_prims"], max(1, info["built_nodes"])
+        bvh = np.zeros((nodes, 2, 4), np.float32)
+        idx = np.zeros(max(1, n), np.int32)
         nn = C.c_uint64()
-        self._chk(self.L.mpt_download_bvh(self.h, _fp(bvh), 2 * n - 1, C.byref(nn), _ip(idx)), "mpt_download_bvh")
-        return bvh[: nn.value].copy(), idx
+        self._chk(self.L.mpt_download_bvh(self.h, _fp(bvh), nodes, C.byref(nn), _ip(idx)), "mpt_download_bvh")
+        return bvh[: nn.value].copy(), idx[:n]
 
     def accel_info(self):
         out = (C.c_uint64 * 8)()

@@ -104,6 +104,7 @@ void Renderer::updateVisibleScene() {
     deviceBuild_ = want == BUILD_GPU;
     if (deviceBuild_) {   // mpt_build_and_upload in buildBuffers(): the tree never exists on the host
         scene_->sortPrimitives();
+        scene_->dropBVH();   // a tree left by an earlier host build (setBuildMode) is not what the device renders: getBVHNodeCount = 0
         deviceDirty_ = true;
         buildBuffers();
         return;

@@ -303,9 +303,15 @@ void Scene::buildBVH() { buildBVH(BuildMode::ReferenceSweep); }
 void Scene::sortPrimitives() {
     // spheres before triangles, original order kept inside each class: primitive ids are the positions
     // after this sort (R/Scene/Scene.h:72-75)
-    std::stable_sort(primitives_.begin(), primitives_.end(), [](const Primitive& a, const Primitive& b) {
-        return static_cast<int>(a.type) < static_cast<int>(b.type);
-    });
+    auto by_type = [](const Primitive& a, const Primitive& b) { return static_cast<int>(a.type) < static_cast<int>(b.type); };
+    if (std::is_sorted(primitives_.begin(), primitives_.end(), by_type)) return;   // (a tree built over this order stays valid)
+    std::stable_sort(primitives_.begin(), primitives_.end(), by_type);
+    dropBVH();   // a host tree indexes the old order
+}
+
+void Scene::dropBVH() {
+    nodes_.clear();
+    primitiveIndices_.clear();
 }
 
 void Scene::adoptBVH(const float* bvh, size_t nodeCount, const int32_t* primIdx) {

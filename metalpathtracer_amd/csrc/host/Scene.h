@@ -37,7 +37,7 @@ public:
     enum class BuildMode {
         ReferenceSweep,  // full-sweep SAH keyed on data0[axis], leaf <= 8 (R/Scene/Scene.h:195-317): same tree
         BinnedCentroid,  // 16-bin SAH on centroids, O(n log n): for large scenes; image-equivalent, not tree-equal
-        GpuLbvh          // built on the GPU (mpt_build_bvh: top-down binned SAH, leaves <= 2; MPT_GPU_BUILD = ploc | lbvh for the
+        GpuLbvh          // built on the GPU (mpt_build_bvh: top-down binned SAH, leaves <= 6 below 8192 primitives and <= 2 from there on — mpt_gpu_leaf_max; MPT_GPU_BUILD = ploc | lbvh for the
                          // Morton-code builders); needs a device (MPT_BUILD_DEVICE, default 0) and throws without one — there
                          // is no CPU fallback
     };
@@ -53,6 +53,7 @@ public:
     const std::vector<Primitive>& getPrimitives() const { return primitives_; }
 
     void sortPrimitives();           // spheres before triangles, stable: the first thing buildBVH does (R/Scene/Scene.h:72-75)
+    void dropBVH();                  // forget the host tree (the device holds another one: Renderer's device build)
     void buildBVH();                 // reference-compatible tree
     void buildBVH(BuildMode mode);
     size_t getBVHNodeCount() const { return nodes_.size(); }

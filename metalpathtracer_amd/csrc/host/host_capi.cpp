@@ -106,6 +106,13 @@ int mpt_scene_build_bvh(mpt_scene* s, int mode) {
         return MPT_OK;
     })
 }
+int mpt_scene_sort_primitives(mpt_scene* s) {
+    if (!s) return MPT_ERR_INVALID_ARG;
+    SCENE_GUARD(MPT_ERR_HIP, {
+        s->sc->sortPrimitives();
+        return MPT_OK;
+    })
+}
 int mpt_scene_counts(const mpt_scene* s, uint64_t* prims, uint64_t* triangles, uint64_t* nodes, int32_t* depth) {
     if (!s) return MPT_ERR_INVALID_ARG;
     const Scene& sc = *s->sc;

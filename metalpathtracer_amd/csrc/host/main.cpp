@@ -25,8 +25,9 @@ static void usage() {
         "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
         "           [--gpus N] [--camera-path FILE [--out-dir runs]] [--bvh reference|binned|gpu|auto]\n"
         "  --bvh             tree builder: the reference's sweep SAH (default with --rng literal, --frames and --camera-path:\n"
-        "                    the drop-in behaviour) or auto (default for batch renders: from 8192 primitives the tree is built\n"
-        "                    on the device, mpt_build_and_upload); binned = the host's 16-bin SAH builder\n"
+        "                    the drop-in behaviour) or auto (default for batch renders: the tree of every scene is built on the\n"
+        "                    device, mpt_build_and_upload, with leaves of <= 6 primitives below 8192 primitives and <= 2 from there\n"
+        "                    on; gpu = the same); binned = the host's 16-bin SAH builder\n"
         "  --frames N        run the reference's frame protocol (N draw() calls, running mean) instead of batch spp\n"
         "  --gpus N          batch mode on GPUs device .. device+N-1: 8x8 pixel tiles interleaved over the GPUs, one RCCL\n"
         "                    reduce(sum) of the HDR framebuffer onto the first (mpt_comm_create_all / mpt_reduce_sum)\n"

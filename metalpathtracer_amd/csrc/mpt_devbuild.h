@@ -263,7 +263,9 @@ __global__ void k_items(int n, const int2* range, const uint32_t* is_leaf, const
 using mpt_lbvh::ld_agent;
 using mpt_lbvh::st4;
 using mpt_lbvh::st_agent;
-// (hand-over between threads as in mpt_lbvh.h k_refit: agent-scope stores and loads, workgroup-scope fences)
+// (hand-over between threads as in mpt_lbvh.h k_refit: agent-scope stores and loads, handoff_release() = an explicit
+//  s_waitcnt vmcnt(0) in front of the arrival counter)
+using mpt_lbvh::handoff_release;
 __global__ void k_own_tree(int n, const int* parent, const int2* child, const uint32_t* is_leaf, const float4* olo, const float4* ohi, int* eff, float4* s_lo,
                            float4* s_hi, int2* s_child, int* arrived, SahState* st) {
     const int leaf = blockIdx.x * blockDim.x + threadIdx.x, TOP = 2 * n - 1;
@@ -277,7 +279,7 @@ __global__ void k_own_tree(int n, const int* parent, const int2* child, const ui
             st->root = e;
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        handoff_release();
         if (atomicAdd(&arrived[p], 1) == 0) return;   // the sibling sub-tree is not finished yet
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int2 c = child[p];

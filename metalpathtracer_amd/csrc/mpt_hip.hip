@@ -110,6 +110,7 @@ struct mpt_ctx {
     float4* d_ref_bvh = nullptr;
     int* d_ref_idx = nullptr;
     uint32_t n_ref_nodes = 0;
+    uint32_t built_leaf_max = 0;     // leaf limit of that tree (mpt_build_info)
     uint32_t ot_stack_depth = 8;     // LDS stack entries per lane (MPT_OT_STACK); deeper entries spill to global memory
     mpt_lbvh::ScratchPool build_pool;  // scratch chunks of the GPU builders, kept between builds (<= 2 GiB)
     OtBudgets ot_budgets = default_ot_budgets();
@@ -726,6 +727,7 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     ctx->d_nodes = ctx->d_prims = ctx->d_mats = ctx->d_acc_nodes = ctx->d_refleaf = ctx->d_always = ctx->d_ref_bvh = nullptr;
     ctx->d_ref_idx = nullptr;
     ctx->n_ref_nodes = 0;
+    ctx->built_leaf_max = 0;
     ctx->have_scene = false;
     auto up = [&](float4** dst, const std::vector<float>& v, size_t min_floats) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max(v.size(), min_floats) * 4);
@@ -1596,6 +1598,7 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     ctx->d_ref_bvh = b.ref_bvh;
     ctx->d_ref_idx = b.ref_idx;
     ctx->n_ref_nodes = b.n_nodes;
+    ctx->built_leaf_max = (uint32_t)leaf_max;
     ctx->n_nodes = b.n_nodes;
     ctx->n_prims = b.n_prims;
     ctx->n_mats = b.n_mats;
@@ -1697,6 +1700,18 @@ extern "C" int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]) {
     if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
     const uint64_t v[8] = {ctx->acc_ok ? 1u : 0u, ctx->n_acc_nodes, ctx->acc_depth, ctx->ot_lds_nodes, ctx->n_always, ctx->n_ref_leaves, ctx->ot_lds_prims,
                            (uint64_t)resolve_pipeline(ctx, MPT_PIPE_AUTO)};
+    memcpy(out, v, sizeof v);
+    return MPT_OK;
+}
+
+extern "C" int mpt_gpu_leaf_max(uint64_t n_prims) { return gpu_leaf_max(n_prims); }
+
+extern "C" int mpt_build_info(mpt_ctx* ctx, uint64_t out[8]) {
+    if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
+    const bool built = ctx->d_ref_bvh != nullptr;
+    const uint64_t v[8] = {built ? ctx->n_prims : 0u, built ? ctx->n_ref_nodes : 0u, built ? ctx->built_leaf_max : 0u, MPT_AUTO_ORDERED_PRIMS,
+                           ctx->n_prims, ctx->n_nodes, ctx->n_mats, 0u};
     memcpy(out, v, sizeof v);
     return MPT_OK;
 }

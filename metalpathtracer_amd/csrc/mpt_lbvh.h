@@ -146,9 +146,21 @@ __global__ void k_hierarchy(const unsigned long long* keys, int n, int2* child, 
     if (i == 0) parent[0] = -1;
 }
 
-// What one thread hands to another inside a kernel goes through agent-scope stores and loads — past the L1 and the XCD's L2 —
-// and the arrival counter is bumped behind a WORKGROUP-scope fence, which only waits for those stores.  (__threadfence()
-// writes the whole L2 back, every thread, every level: 5.2 ms for a 1 M-primitive refit against 0.2.)
+// What one thread hands to another inside a kernel (k_refit here, k_own_tree in mpt_devbuild.h) goes through agent-scope
+// (sc1) stores and loads — past the L1 and the XCD's L2 — and handoff_release() orders them in front of the arrival counter:
+//   * the ORDERING MECHANISM is the explicit `s_waitcnt vmcnt(0)`: on gfx9 vmcnt covers stores too, so every sc1 store this
+//     thread has issued has been acknowledged at the coherence point before the relaxed agent-scope atomicAdd is issued;
+//   * the workgroup-scope release fence in front of it is there for the COMPILER only (it may not sink the stores below
+//     it); in hardware it is just `s_waitcnt lgkmcnt(0)` and synchronises with nobody outside the workgroup;
+//   * the consumer is the thread whose atomicAdd returns 1: its sc1 loads are issued after that value has come back (the
+//     branch needs it), and sc1 loads do not hit in the non-coherent L1 / L2 lines.
+// An agent-scope release (or __threadfence()) would be the textbook form, but it writes the XCD's whole L2 back — per
+// thread, per level: 5.2 ms for a 1 M-primitive refit against 0.2.  tests/test_build_asm.py checks in the built code
+// object that a `s_waitcnt vmcnt(0)` stands between the last store and the atomic of both kernels.
+__device__ __forceinline__ void handoff_release() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ float4 ld4(const float4* p) {
     const float* f = (const float*)p;
     return make_float4(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
@@ -176,7 +188,7 @@ __global__ void k_refit(const uint32_t* vals, const float4* blo, const float4* b
     st4(nhi + (n - 1) + p, h.x, h.y, h.z);
     int node = parent[(n - 1) + p];
     while (node >= 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        handoff_release();
         if (atomicAdd(&arrived[node], 1) == 0) return;  // the sibling subtree is not finished yet
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int2 c = child[node];

@@ -18,7 +18,7 @@ BVH_REFERENCE_SWEEP, BVH_BINNED_CENTROID, BVH_GPU_LBVH = 0, 1, 2
 
 SYMBOLS = (
     "mpt_scene_create", "mpt_scene_destroy", "mpt_scene_clear", "mpt_scene_load_xml", "mpt_scene_add_primitive",
-    "mpt_scene_build_bvh", "mpt_scene_counts", "mpt_scene_copy_buffers", "mpt_camera_reset_values",
+    "mpt_scene_build_bvh", "mpt_scene_sort_primitives", "mpt_scene_counts", "mpt_scene_copy_buffers", "mpt_camera_reset_values",
     "mpt_camera_viewport", "mpt_host_random_float", "mpt_renderer_create", "mpt_renderer_destroy",
     "mpt_renderer_drawable_size_will_change", "mpt_renderer_set_params", "mpt_renderer_draw", "mpt_renderer_input",
     "mpt_renderer_read_frame", "mpt_renderer_render_batch", "mpt_renderer_read_sum", "mpt_renderer_clear_sum",
@@ -44,6 +44,7 @@ def load():
     L.mpt_scene_load_xml.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
     L.mpt_scene_add_primitive.argtypes = [vp, C.c_int, fp, fp, fp, fp]
     L.mpt_scene_build_bvh.argtypes = [vp, C.c_int]
+    L.mpt_scene_sort_primitives.argtypes = [vp]
     L.mpt_scene_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_int32)]
     L.mpt_scene_copy_buffers.argtypes = [vp, fp, fp, fp, ip]
@@ -121,6 +122,12 @@ class Scene:
         if rc:
             raise ValueError("mpt_scene_build_bvh: %d" % rc)
 
+    def sortPrimitives(self):
+        """Scene::sortPrimitives: spheres first, stable — all that mpt_build_and_upload needs of buildBVH."""
+        rc = self.L.mpt_scene_sort_primitives(self.h)
+        if rc:
+            raise ValueError("mpt_scene_sort_primitives: %d" % rc)
+
     def _counts(self):
         p, t, n, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
         self.L.mpt_scene_counts(self.h, C.byref(p), C.byref(t), C.byref(n), C.byref(d))
@@ -183,8 +190,7 @@ def make_ready(ctx, scene, bvh=BVH_REFERENCE_SWEEP):
     Returns the (bvh, prims, mats, prim_idx) arrays in the reference's buffer format — for BVH_DEVICE the tree comes back
     from the device (mpt_download_bvh): what the oracle walks to render the same image."""
     if bvh == BVH_DEVICE:
-        if scene.getBVHNodeCount() == 0:
-            scene.buildBVH(BVH_REFERENCE_SWEEP)      # (sorts the primitives spheres first, as every builder does; the tree is not used)
+        scene.sortPrimitives()                       # spheres first, as every builder does; no host tree is built
         prims, mats = scene.packed_primitives()
         ctx.build_and_upload(prims, mats)
         tree, idx = ctx.download_bvh()

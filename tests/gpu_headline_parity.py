@@ -1,16 +1,26 @@
 """The headline configuration itself (scene.xml, 1920x1080, 256 spp, depth 8, philox seed (1,0)): HIP image vs the CPU
-oracle, every float of the HDR sum compared bit for bit (the oracle needs ~8 s on 16 threads for its 890 M rays)."""
+oracle, every float of the HDR sum compared bit for bit (the oracle needs ~8 s on 16 threads for its 890 M rays).
+
+  BVH=reference (default)  Scene::buildBVH (the reference's sweep SAH, R/Scene/Scene.h:195-317) + mpt_upload_scene
+  BVH=device               host.make_ready(ctx, sc, host.BVH_DEVICE) = mpt_build_and_upload — the route bench.py's default
+                           line renders — and the oracle walks the tree that comes back through mpt_download_bvh
+  CROSS=1 (with BVH=device) also renders the reference's tree and prints / checks the per-pixel L2 and the ray-count delta
+                           between the two trees' images at full size: the trees are equal up to ties (a ray that hits two
+                           primitives at the same t keeps the one its tree visits first), so the images are NOT bit-identical
+                           and the stated tolerance of north_star (per-pixel L2 < 1e-3) is what is asserted."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from metalpathtracer_amd import capi, host
 from oracle import binding as ob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BVH = os.environ.get("BVH", "reference")
 sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", "scene.xml"), sc); assert st == 0
-sc.buildBVH(); buf = sc.buffers()
 W, H, spp = 1920, 1080, int(os.environ.get("SPP", "256"))
+ctx = capi.Context(0)
+buf = host.make_ready(ctx, sc, host.BVH_DEVICE if BVH == "device" else host.BVH_REFERENCE_SWEEP)
 u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount())
-ctx = capi.Context(0); ctx.upload_scene(*buf); ctx.resize(W, H); ctx.set_uniforms(u); ctx.clear_sum(); ctx.reset_stats()
+ctx.resize(W, H); ctx.set_uniforms(u); ctx.clear_sum(); ctx.reset_stats()
 SCENE_PIPE = int(os.environ.get("PIPE", str(capi.DEFAULT_PIPELINE)))
 ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=spp, seed=(1, 0), pipeline=SCENE_PIPE)
 got = ctx.read_sum(); s = ctx.stats()
@@ -20,7 +30,21 @@ ref, ct = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG
 dt = time.time() - t0
 same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 l2 = float(np.sqrt(np.mean(np.sum((got[..., :3] / spp - ref[..., :3] / spp) ** 2, -1))))
-print("pipeline %d, re-traced in reference order %d, parked %d" % (SCENE_PIPE, s["exact_retraces"], s["tree_parked"]))
+print("tree %s (%d nodes), pipeline %d, re-traced in reference order %d, parked %d" % (BVH, len(buf[0]), SCENE_PIPE, s["exact_retraces"], s["tree_parked"]))
 print("GPU %.1f ms (%d rays), oracle %.1f s (%d rays): bit-identical=%s, per-pixel L2 = %.3g, differing floats = %d" % (
     s["total_ms"], s["rays"], dt, ct["rays"], same, l2, int((got != ref).sum())))
-sys.exit(0 if same and s["rays"] == ct["rays"] else 1)
+ok = same and s["rays"] == ct["rays"]
+if BVH == "device" and os.environ.get("CROSS"):
+    sc2 = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", "scene.xml"), sc2); assert st == 0
+    host.make_ready(ctx, sc2, host.BVH_REFERENCE_SWEEP)
+    ctx.clear_sum(); ctx.reset_stats()
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=spp, seed=(1, 0), pipeline=SCENE_PIPE)
+    other = ctx.read_sum(); s2 = ctx.stats()
+    d = (got[..., :3].astype(np.float64) - other[..., :3].astype(np.float64)) / spp
+    cross = float(np.sqrt((d * d).sum(-1).mean()))
+    npix = int((np.abs(d).max(-1) > 0).sum())
+    print("device-built tree vs the reference's tree at full size: per-pixel L2 = %.3g, max |d| = %.3g, pixels that differ = %d of %d, "
+          "rays %d vs %d (delta %+d)" % (cross, float(np.abs(d).max()), npix, W * H, s["rays"], s2["rays"], s["rays"] - s2["rays"]))
+    ok = ok and cross < 1e-3
+    print("cross-tree L2 < 1e-3: %s" % (cross < 1e-3))
+sys.exit(0 if ok else 1)

@@ -290,3 +290,53 @@ def test_auto_keeps_the_reference_order_for_the_literal_rng(gpu_ctx):
     gpu_ctx.reset_stats()
     gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=1)
     assert gpu_ctx.stats()["tree_parked"] > 0
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_adversarial_scenes_render_the_same_image_on_both_walks(gpu_ctx, case):
+    """north_star's gate on the one class of rays where the two walks may differ (the reference's own grazing artefacts,
+    include/mpt.h MPT_PIPE_ORDERED): every adversarial family rendered as an IMAGE — camera inside the cloud, 640x360 x 16 spp,
+    depth 8, sky light — once by the closest-first pipeline (what MPT_PIPE_AUTO runs for a scene of this size with the philox
+    RNG: asserted) and once by the reference-order pipeline (k_wavelocal).  Stated tolerance: per-pixel L2 < 1e-3 on the resolved
+    image; the number of pixels that differ at all, the largest difference and the ray counts are printed (and asserted small:
+    a differing ray changes one of a pixel's 16 samples).  The device-built tree (what --bvh auto renders) and the reference's
+    own tree are both rendered."""
+    from metalpathtracer_amd import capi, host
+    name, make, spheres, _, spread = CASES[case]
+    rng = np.random.default_rng(500 + case)
+    tris = make(rng)
+    W, H, spp = 640, 360, 16
+    for tree in (host.BVH_DEVICE, host.BVH_REFERENCE_SWEEP):
+        sc = host.Scene()
+        for c, r in spheres:
+            sc.addSphere([float(x) for x in c], float(r), albedo=(0.9, 0.6, 0.3))
+        for k, t in enumerate(tris):
+            sc.addTriangle([float(x) for x in t[0]], [float(x) for x in t[1]], [float(x) for x in t[2]],
+                           albedo=(0.8, 0.8, 0.8) if k % 7 else (0.9, 0.3, 0.2))
+        host.make_ready(gpu_ctx, sc, tree)
+        info = gpu_ctx.accel_info()
+        assert info["ordered_ok"] == 1 and info["auto_pipeline"] == capi.PIPE_ORDERED, (name, info)
+        cam = dict(pos=(0.0, 0.05 * spread, 0.0), fwd=(0.28603878, -0.09534626, -0.95346259), up=(0.0, 1.0, 0.0), vfov=70.0)
+        gpu_ctx.resize(W, H)
+        gpu_ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam))
+        img, rays = {}, {}
+        for pipe in (capi.PIPE_AUTO, capi.PIPE_WAVELOCAL):
+            gpu_ctx.clear_sum()
+            gpu_ctx.reset_stats()
+            gpu_ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=spp, seed=(3, 9), pipeline=pipe)
+            img[pipe] = gpu_ctx.read_sum() / spp
+            st = gpu_ctx.stats()
+            rays[pipe] = st["rays"]
+            assert (st["tree_parked"] > 0) == (pipe == capi.PIPE_AUTO), (name, pipe, st)   # AUTO really ran k_ordered
+        a, b = img[capi.PIPE_AUTO], img[capi.PIPE_WAVELOCAL]
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+        l2 = float(np.sqrt((d * d).sum(-1).mean()))
+        npix = int((np.abs(d).max(-1) > 0).sum())
+        hit_frac = float((b[..., 3] < 1.0).mean())            # alpha counts sky terminations: < 1 = some sample ended elsewhere
+        print("%-45s tree %d: per-pixel L2 %.3g, pixels that differ %d of %d, max |d| %.3g, rays %d vs %d, non-sky pixels %.0f %%"
+              % (name, tree, l2, npix, W * H, float(np.abs(d).max()), rays[capi.PIPE_AUTO], rays[capi.PIPE_WAVELOCAL], 100 * hit_frac))
+        assert l2 < 1e-3, (name, tree, l2, npix)
+        assert npix <= 1e-4 * W * H * spp, (name, tree, npix)          # (observed: 0 — natural rays do not graze at 1e-5 rad)
+        assert abs(rays[capi.PIPE_AUTO] - rays[capi.PIPE_WAVELOCAL]) <= 1e-5 * rays[capi.PIPE_WAVELOCAL] + 8
+        assert b[..., :3].std() > 0.01, name                           # a picture, not a flat sky

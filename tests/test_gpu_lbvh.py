@@ -10,8 +10,15 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 
+def capi_leaf(n):
+    from metalpathtracer_amd import capi
+    return capi.gpu_leaf_max(n)
+
+
 def _check_tree(bvh, idx, prims):
+    from metalpathtracer_amd import capi
     n_nodes, P = bvh.shape[0], prims.shape[0]
+    leaf_max = capi.gpu_leaf_max(P)                                 # asked of the library (mpt_gpu_leaf_max), not re-derived here
     lf = bvh[:, 3].copy().view(np.int32)
     cnt = bvh[:, 7].copy().view(np.int32)
     assert sorted(idx.tolist()) == list(range(P))                  # every primitive in exactly one slot
@@ -30,7 +37,7 @@ def _check_tree(bvh, idx, prims):
         depth_max = max(depth_max, depth[n])
         if cnt[n] > 0:
             leaves += 1
-            assert cnt[n] <= (6 if P < 8192 else 2) and 0 <= lf[n] and lf[n] + cnt[n] <= P   # (leaf size: mpt_hip.hip gpu_leaf_max)
+            assert cnt[n] <= leaf_max and 0 <= lf[n] and lf[n] + cnt[n] <= P
             covered[lf[n]:lf[n] + cnt[n]] += 1
             for k in range(cnt[n]):                                # the leaf box contains its primitives' boxes
                 p = prims[idx[lf[n] + k]]
@@ -98,7 +105,7 @@ def test_gpu_build_small_inputs_and_determinism(gpu_ctx, builder, monkeypatch):
         bvh2, idx2, _ = gpu_ctx.build_bvh(prims)
         np.testing.assert_array_equal(bvh.view(np.uint32), bvh2.view(np.uint32))
         np.testing.assert_array_equal(idx, idx2)
-        assert (n <= 6) == (bvh.shape[0] == 1)                       # scenes this small get leaves of <= 6 primitives (2 from 8192 on)
+        assert (n <= capi_leaf(n)) == (bvh.shape[0] == 1)            # a scene that fits one leaf (mpt_gpu_leaf_max) is one node
 
 
 @pytest.mark.parametrize("builder", ["sah", "sah+refit", "sah+sah", "ploc", "lbvh"])
@@ -449,3 +456,61 @@ def test_builders_at_the_kernels_size_boundaries(gpu_ctx, builder, monkeypatch):
             np.testing.assert_array_equal(t0.view(np.uint32), t1.view(np.uint32))
             np.testing.assert_array_equal(p0, p1)
         assert n < 257 or (p0 >= 0).sum() > m // 50, (n, n_sph)
+
+
+def test_config4_at_its_real_size_on_the_device_built_tree(gpu_ctx, tmp_path):
+    """BASELINE.json configs[4] at its real size on the route `--bvh auto` takes: the 1,000,003-primitive scene (two 500 K-triangle
+    height fields, one of them glass; mirror and glass spheres; an emitter) built ON THE DEVICE, 1920x1080, one GPU's 1/8 tile
+    shard, 4096 spp, depth 16, Scatter.h BSDFs = 1.06 G paths in one pass: deterministic, and the closest-first pipeline
+    (MPT_PIPE_AUTO for this scene) gives bit for bit what the reference-order pipeline gives; then, at 4 spp, a 32-row band
+    of the unsharded image against the oracle walking the tree that mpt_download_bvh returns."""
+    import time
+    from metalpathtracer_amd import capi, host
+    from test_gpu_parity import _heightfield_obj
+    _heightfield_obj(str(tmp_path / "hf.obj"), 501, seed=1)
+    (tmp_path / "big.xml").write_text("""<Scene>
+  <Mesh file="hf.obj" position="0,-10,-30" scale="1.0" albedo="0.7,0.7,0.75" emission="0,0,0" materialType="0" emissionPower="0"/>
+  <Mesh file="hf.obj" position="0,35,-60" scale="0.6" albedo="1,1,1" emission="0,0,0" materialType="1.5" emissionPower="0"/>
+  <Sphere position="-15,18,-10" radius="9" albedo="0.95,0.95,0.95" emission="0,0,0" materialType="-1" emissionPower="0"/>
+  <Sphere position="15,18,-10" radius="9" albedo="1,1,1" emission="0,0,0" materialType="1.5" emissionPower="0"/>
+  <Sphere position="0,60,-20" radius="10" albedo="0,0,0" emission="1,0.9,0.7" materialType="0" emissionPower="5"/>
+</Scene>""")
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(str(tmp_path / "big.xml"), sc)
+    assert st == 0 and sc.getPrimitiveCount() == 1000003, log
+    buf = host.make_ready(gpu_ctx, sc, host.BVH_DEVICE)
+    info = gpu_ctx.accel_info()
+    assert info["ordered_ok"] == 1 and info["auto_pipeline"] == capi.PIPE_ORDERED and gpu_ctx.build_info()["built_leaf_max"] == 2
+    W, H = 1920, 1080
+    u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount())
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_uniforms(u)
+    kw = dict(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_SCATTER, max_depth=16, seed=(1, 0))
+    shard = dict(shard_rank=3, shard_count=8)
+    img, ms = {}, {}
+    for tag, pipe in (("auto", capi.PIPE_AUTO), ("again", capi.PIPE_AUTO), ("reference order", capi.PIPE_WAVELOCAL)):
+        gpu_ctx.clear_sum()
+        gpu_ctx.reset_stats()
+        gpu_ctx.render(sample_count=4096, pipeline=pipe, **shard, **kw)
+        s = gpu_ctx.stats()
+        assert s["trace_launches"] == 1 and s["paths"] == 4050 * 64 * 4096        # 240 x 135 tiles / 8 ranks: ONE pass of 1.06 G paths
+        assert (s["tree_parked"] > 0) == (pipe == capi.PIPE_AUTO)
+        img[tag], ms[tag] = gpu_ctx.read_sum(), (s["total_ms"], s["rays"])
+    print("config 4 shard: k_ordered %.1f ms (%.2f Grays/s), k_wavelocal %.1f ms, %d rays" % (
+        ms["auto"][0], ms["auto"][1] / ms["auto"][0] / 1e6, ms["reference order"][0], ms["auto"][1]))
+    assert np.isfinite(img["auto"]).all() and img["auto"][..., 3].max() > 0
+    np.testing.assert_array_equal(img["auto"].view(np.uint32), img["again"].view(np.uint32))              # deterministic
+    np.testing.assert_array_equal(img["auto"].view(np.uint32), img["reference order"].view(np.uint32))    # closest-first == reference order
+    assert ms["auto"][1] == ms["reference order"][1]
+    owned = img["auto"][..., 3] > 0
+    ty, tx = np.nonzero(owned)
+    assert set(((ty // 8) * 240 + tx // 8) % 8) == {3}                                # only rank 3's tiles were touched
+    del img
+    # ---- a band of rows against the oracle on the downloaded tree (4 spp, unsharded) ------------------------------------------
+    rows = (600, 632)                                                                 # through the lower height field
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(sample_count=4, **kw)
+    whole = gpu_ctx.read_sum()
+    ref, _ = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG_PHILOX, bsdf_mode=ob.BSDF_SCATTER, max_depth=16,
+                       accumulate=1, sample_count=4, seed=(1, 0), rows=rows, threads=8)
+    np.testing.assert_array_equal(whole[rows[0]:rows[1]].view(np.uint32), ref[rows[0]:rows[1]].view(np.uint32))

@@ -575,14 +575,26 @@ def test_randomised_cases_bit_exact():
     assert "60 cases, 0 mismatches" in r.stdout
 
 
-@pytest.mark.parametrize("pipe", ["4", "3"])
-def test_headline_config_is_bit_identical_to_the_oracle(pipe):
-    """BASELINE.json configs[1] itself — scene.xml, 1920x1080, 256 spp, depth 8 (890,385,105 rays): every float of the
-    HDR sum equals the oracle's (tests/gpu_headline_parity.py; the oracle takes ~8 s on the GPU box's 16 host threads).
-    Once with the default pipeline choice (AUTO = what bench.py runs), once with the closest-first pipeline."""
+@pytest.mark.parametrize("pipe,bvh", [("4", "reference"), ("3", "reference"), ("4", "device"), ("3", "device")])
+def test_headline_config_is_bit_identical_to_the_oracle(pipe, bvh):
+    """BASELINE.json configs[1] itself — scene.xml, 1920x1080, 256 spp, depth 8 (890,385,105 rays on the reference's tree):
+    every float of the HDR sum equals the oracle's (tests/gpu_headline_parity.py; the oracle takes ~8 s on the GPU box's 16
+    host threads).  On the reference's own tree through mpt_upload_scene (the drop-in route) AND on the device-built tree
+    through mpt_build_and_upload (what bench.py's default line renders: the oracle walks the tree that mpt_download_bvh
+    returns), each once with the default pipeline choice (AUTO = what bench.py runs) and once with the closest-first
+    pipeline.  The device-tree AUTO case also renders the reference's tree and asserts that the two trees' images — equal up
+    to ties — are within north_star's per-pixel L2 < 1e-3 at the full 256 spp."""
     import os, subprocess, sys
     from conftest import ROOT
+    env = dict(os.environ, PIPE=pipe, BVH=bvh)
+    if bvh == "device" and pipe == "4":
+        env["CROSS"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_headline_parity.py")], capture_output=True,
-                       text=True, timeout=1200, env=dict(os.environ, PIPE=pipe))
+                       text=True, timeout=1200, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    assert "bit-identical=True" in r.stdout and "890385105 rays" in r.stdout
+    assert "bit-identical=True" in r.stdout
+    if bvh == "reference":
+        assert "890385105 rays" in r.stdout
+    if "CROSS" in env:
+        assert "cross-tree L2 < 1e-3: True" in r.stdout
+    print(r.stdout)
