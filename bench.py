@@ -115,7 +115,7 @@ def host_cores():
     return min(n, cap) if cap > 0 else n
 
 
-def cpu_baseline(args, scene_buffers, prim_count, tri_count):
+def cpu_baseline(args, scene_buffers, prim_count, tri_count, reference_buffers=None):
     """Time the CPU oracle on all host cores on a bounded sample (same scene, size, depth, RNG; fewer spp).
     Also returns the per-ray work counters that price the algorithmic bytes per ray (reference traversal)."""
     from oracle import binding as ob
@@ -136,30 +136,73 @@ def cpu_baseline(args, scene_buffers, prim_count, tri_count):
     _, c1 = ob.render(u, scene_buffers, rng_mode=ob.RNG_PHILOX, max_depth=args.depth, accumulate=1, sample_count=spp1,
                       seed=(1, 0), threads=1)
     dt1 = time.perf_counter() - t0
-    return dict(value=ct["rays"] / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
-                sample="%dx%d, %d spp, depth %d, philox seed (1,0): %d rays in %.2f s on %d threads"
-                       % (args.width, args.height, spp, args.depth, ct["rays"], dt, cores),
-                single_core={"value": c1["rays"] / dt1 / 1e6, "unit": "Mrays/s",
-                             "sample": "%d spp: %d rays in %.2f s on 1 thread" % (spp1, c1["rays"], dt1)}), (n_node, n_prim, h)
+    out = dict(value=ct["rays"] / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
+               tree={"reference": "the reference's own tree (Scene::buildBVH sweep SAH, R/Scene/Scene.h:195-317)",
+                     "binned": "the host binned-SAH tree", "gpu": "the GPU-built tree (mpt_build_bvh)",
+                     "device": "the device-built tree the GPU leg renders (mpt_build_and_upload, read back by mpt_download_bvh) — same arrays, "
+                               "same walk order on both sides"}[args.bvh],
+               sample="%dx%d, %d spp, depth %d, philox seed (1,0): %d rays in %.2f s on %d threads"
+                      % (args.width, args.height, spp, args.depth, ct["rays"], dt, cores),
+               single_core={"value": c1["rays"] / dt1 / 1e6, "unit": "Mrays/s",
+                            "sample": "%d spp: %d rays in %.2f s on 1 thread" % (spp1, c1["rays"], dt1)})
+    if reference_buffers is not None:   # the reference's path on the reference's tree: what "the reference's CPU path" would walk
+        t0 = time.perf_counter()
+        _, cr = ob.render(u, reference_buffers, rng_mode=ob.RNG_PHILOX, max_depth=args.depth, accumulate=1, sample_count=spp,
+                          seed=(1, 0), threads=cores)
+        dtr = time.perf_counter() - t0
+        out["reference_tree"] = {"value": cr["rays"] / dtr / 1e6, "unit": "Mrays/s", "cores": cores,
+                                 "sample": "%d spp: %d rays in %.2f s on %d threads, %.2f node pops and %.2f primitive tests per ray"
+                                           % (spp, cr["rays"], dtr, cores, cr["node_pops"] / cr["rays"], cr["prim_tests"] / cr["rays"])}
+    return out, (n_node, n_prim, h)
 
 
 CORNELL_CAM = dict(pos=(0.0, 1.0, 3.4), fwd=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), vfov=40.0)
+BVH_CODE = {"reference": 0, "binned": 1, "gpu": 2, "device": 3}
+
+
+def roofline_from_profile(kernel, workload, rays, seconds):
+    """The fractions of one workload: per-ray counters of the committed profile of THIS workload and THIS build (counter_profile)
+    x the rays traced in `seconds` of wall time.  Returns (dict, why): dict is None when no such profile is committed."""
+    prof, why = counter_profile(kernel, workload)
+    if not prof:
+        return None, why
+    valu_rate = prof["valu_per_ray"] * rays / seconds / 1e9                  # G wave64 instructions per second
+    valu_peak = N_SIMD * MAX_CLOCK_GHZ / 2.0                                 # 1024 SIMD-32s, one wave64 instruction per 2 cycles, 2.4 GHz
+    hbm_rate = prof["hbm_bytes_per_ray"] * rays / seconds / 1e9
+    salu_rate = prof["salu_per_ray"] * rays / seconds / 1e9
+    return {"prof": prof, "valu_rate": valu_rate, "valu_peak": valu_peak, "valu_frac": valu_rate / valu_peak,
+            "hbm_rate": hbm_rate, "hbm_frac": hbm_rate / HBM_PEAK_GBS, "salu_rate": salu_rate, "salu_frac": salu_rate / (N_CU * MAX_CLOCK_GHZ)}, {}
 
 
 def extra_workloads(ctx, capi, host, depth):
-    """Untimed extras (N = 1), like serial_ms_per_render: ONE serial 1920x1080 x 256 spp render of north_star's "synthetic
-    Cornell-style scene" and of bunny x20 (BASELINE.json configs[2]'s scene, on the tree the Renderer picks for it), so that
-    the driver's record carries them.  HIP-event time of the whole render, best of two after a warm-up."""
+    """Untimed extras (N = 1), like serial_ms_per_render: ONE serial render each of
+      * north_star's "synthetic Cornell-style scene" and bunny x20 (BASELINE.json configs[2]'s scene) at 1920x1080 x 256 spp on the
+        tree the Renderer's throughput mode builds for them (device build),
+      * scene.xml on the REFERENCE's own tree (Scene::buildBVH sweep SAH + mpt_upload_scene: the drop-in route) at the headline size,
+      * configs[4] at its real size: the 1,000,003-primitive scene, 1920x1080 x 4096 spp, depth 16, Scatter.h BSDFs, one GPU's 1/8
+        tile shard (1.06 G paths),
+    so that the driver's record carries them.  HIP-event time of the whole render, best of two after a warm-up; each with the
+    fraction of the vector-issue peak from its OWN committed counter profile (or profile_missing / profile_stale)."""
+    import tempfile
     import time
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config4_scene
     out = []
-    for name, xml, builder, cam in (("cornell.xml", "cornell.xml", "device", CORNELL_CAM), ("bunny20.xml", "bunny20.xml", "device", None)):
+    tmp = tempfile.mkdtemp(prefix="mpt_cfg4_")
+    cases = (("cornell.xml", os.path.join(ROOT, "assets", "cornell.xml"), "device", CORNELL_CAM, 256, depth, capi.BSDF_LAMBERT, 1),
+             ("bunny20.xml", os.path.join(ROOT, "assets", "bunny20.xml"), "device", None, 256, depth, capi.BSDF_LAMBERT, 1),
+             ("scene.xml", os.path.join(ROOT, "assets", "scene.xml"), "reference", None, 256, depth, capi.BSDF_LAMBERT, 1),
+             ("config4", None, "device", None, 4096, 16, capi.BSDF_SCATTER, 8))
+    for name, xml, builder, cam, spp, dep, bsdf, shards in cases:
+        if xml is None:
+            xml = config4_scene.write(tmp)
         sc = host.Scene()
-        st, log = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", xml), sc)
+        st, log = host.SceneLoader.LoadSceneFromXML(xml, sc)
         if st != 0:
             out.append({"workload": name, "error": log[-200:]})
             continue
         t0 = time.perf_counter()
-        if builder == "device":                      # what the Renderer does for a scene of this size: build -> render on the device
+        if builder == "device":                      # what the Renderer does in its throughput mode: build -> render on the device
             sc.sortPrimitives()
             prims, mats = sc.packed_primitives()
             t0 = time.perf_counter()
@@ -168,21 +211,35 @@ def extra_workloads(ctx, capi, host, depth):
             sc.buildBVH(host.BVH_REFERENCE_SWEEP)
             ctx.upload_scene(*sc.buffers())
         setup_ms = (time.perf_counter() - t0) * 1e3
-        W, H, spp = 1920, 1080, 256
+        W, H = 1920, 1080
         ctx.resize(W, H)
         ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam))
+        pipe = ctx.accel_info()["auto_pipeline"]
         best = None
         for k in range(3):
             ctx.reset_stats()
-            ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=capi.BSDF_LAMBERT, max_depth=depth, pipeline=capi.PIPE_AUTO, seed=(1, 0),
-                       sample_begin=k * spp, sample_count=spp)
+            ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=dep, pipeline=capi.PIPE_AUTO, seed=(1, 0),
+                       sample_begin=k * spp, sample_count=spp, shard_rank=0, shard_count=shards)
             s = ctx.stats()
             if k and (best is None or s["total_ms"] < best["total_ms"]):
                 best = s
-        out.append({"workload": "%s %dx%d x %d spp, depth %d, one serial render" % (name, W, H, spp, depth),
-                    "prims": sc.getPrimitiveCount(), "bvh_builder": builder, "build_and_upload_ms": setup_ms,
-                    "pipeline": PIPE_NAMES[ctx.accel_info()["auto_pipeline"]], "ms_per_render": best["total_ms"],
-                    "mrays_per_s": best["rays"] / best["total_ms"] / 1e3, "rays": best["rays"], "paths": best["paths"]})
+        e = {"workload": "%s %dx%d x %d spp, depth %d, %sone serial render" % (name, W, H, spp, dep, "1/%d tile shard, " % shards if shards > 1 else ""),
+             "prims": sc.getPrimitiveCount(), "bvh_builder": builder, "build_and_upload_ms": setup_ms,
+             "pipeline": PIPE_NAMES[pipe], "ms_per_render": best["total_ms"],
+             "mrays_per_s": best["rays"] / best["total_ms"] / 1e3, "rays": best["rays"], "paths": best["paths"]}
+        workload = {"scene": name if name != "config4" else "config4", "width": W, "height": H, "spp": spp, "depth": dep,
+                    "bvh": BVH_CODE[builder], "env": capi.knob_env()}
+        r, why = roofline_from_profile(PIPE_KERNEL[pipe], workload, best["rays"], best["total_ms"] * 1e-3)
+        if r:
+            e["roofline"] = {"kernel": PIPE_KERNEL[pipe], "bound": "valu" if r["valu_frac"] >= r["hbm_frac"] else "hbm",
+                             "frac": max(r["valu_frac"], r["hbm_frac"]), "valu_frac": r["valu_frac"], "hbm_frac": r["hbm_frac"],
+                             "valu_instr_per_ray": r["prof"]["valu_per_ray"], "hbm_bytes_per_ray": r["prof"]["hbm_bytes_per_ray"],
+                             "wave_cycles_split": r["prof"]["wave_cycles_split"], "profile": r["prof"]["file"]}
+        else:
+            e["roofline"] = dict(kernel=PIPE_KERNEL[pipe], frac=None, **why)
+        out.append(e)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -320,7 +377,14 @@ def main():
         }
         n_node, n_prim, h = 7.52, 3.59, 0.405   # SURVEY.md App. C.5 (used only if the CPU leg is skipped)
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
-            out["cpu_baseline"], (n_node, n_prim, h) = cpu_baseline(args, buffers, P, T)
+            ref_buffers = None
+            if args.bvh != "reference":          # a second CPU figure on the reference's own tree (what the reference itself would walk)
+                sc_ref = host.Scene()
+                st_ref, _ = host.SceneLoader.LoadSceneFromXML(args.scene, sc_ref)
+                if st_ref == 0:
+                    sc_ref.buildBVH(host.BVH_REFERENCE_SWEEP)
+                    ref_buffers = sc_ref.buffers()
+            out["cpu_baseline"], (n_node, n_prim, h) = cpu_baseline(args, buffers, P, T, ref_buffers)
         b_ray = B_QUEUE + 32.0 * n_node + 52.0 * n_prim + 32.0 * h
         out["serial_ms_per_render"] = serial_ms
         if world == 1 and not args.no_extra_workloads:
@@ -330,43 +394,48 @@ def main():
             rays_per_launch = rays_local / launches
             sec_per_launch = kernel_ms * 1e-3 / launches
             workload = {"scene": os.path.basename(args.scene), "width": W, "height": H, "spp": spp, "depth": args.depth,
-                        "bvh": {"reference": 0, "binned": 1, "gpu": 2, "device": 3}[args.bvh], "env": capi.knob_env()}
-            prof, why = counter_profile(PIPE_KERNEL[pipe], workload)
+                        "bvh": BVH_CODE[args.bvh], "env": capi.knob_env()}
             rf = {"kernel": PIPE_KERNEL[pipe], "launches": launches, "avg_launch_ms": kernel_ms / launches,
                   "rays_per_launch": rays_per_launch}
-            if prof:
-                # vector-ALU issue: wave64 instructions per second vs 1024 SIMD-32s issuing one every 2 cycles at the chip's
-                # 2.4 GHz (MI355X_MICROARCH.md).  The clock the kernel actually held is lower (DVFS): that fraction is
-                # reported next to it, it is not the headline.
-                valu_rate = prof["valu_per_ray"] * rays_per_launch / sec_per_launch / 1e9            # G wave-instr/s
-                valu_peak = N_SIMD * MAX_CLOCK_GHZ / 2.0
-                hbm_bytes = prof["hbm_bytes_per_ray"] * rays_per_launch
-                hbm_rate = hbm_bytes / sec_per_launch / 1e9
-                valu_frac, hbm_frac = valu_rate / valu_peak, hbm_rate / HBM_PEAK_GBS
-                if valu_frac >= hbm_frac:
-                    rf.update(bound="valu", achieved=valu_rate, peak=valu_peak, unit="G wave64-instr/s", frac=valu_frac)
+            # THE fraction: this rank's rays of the timed region over the WALL time of the timed region (the same clock `value` is
+            # quoted on) — what the chip delivered.  The K launches of the region overlap in pairs on the two render lanes, so the
+            # HIP-event duration of a single launch is longer than ms_per_step; fractions per launch are kept under `per_launch`.
+            r, why = roofline_from_profile(PIPE_KERNEL[pipe], workload, rays_local, elapsed)
+            if r:
+                prof = r["prof"]
+                if r["valu_frac"] >= r["hbm_frac"]:
+                    rf.update(bound="valu", achieved=r["valu_rate"], peak=r["valu_peak"], unit="G wave64-instr/s", frac=r["valu_frac"])
                 else:
-                    rf.update(bound="hbm", achieved=hbm_rate, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac)
-                rf["traffic"] = hbm_bytes
-                rf["valu"] = {"achieved": valu_rate, "peak": valu_peak, "unit": "G wave64-instr/s", "frac": valu_frac,
-                              "frac_at_measured_clock": valu_rate / (N_SIMD * prof["clock_ghz"] / 2.0),
+                    rf.update(bound="hbm", achieved=r["hbm_rate"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r["hbm_frac"])
+                rf["basis"] = ("per-ray counters of the committed profile x the %d rays of the timed region / its %.4f s of wall time (n_gpus = 1: "
+                               "the chip's rate; n_gpus > 1: rank 0's share over the job's wall time)" % (rays_local, elapsed))
+                rf["traffic"] = prof["hbm_bytes_per_ray"] * rays_per_launch          # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)
+                rf["valu"] = {"achieved": r["valu_rate"], "peak": r["valu_peak"], "unit": "G wave64-instr/s", "frac": r["valu_frac"],
                               "measured_clock_ghz": prof["clock_ghz"],
                               "measured_clock_note": "GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the PROFILED launch (profiled passes "
                                                      "clock lower than un-profiled ones)",
+                              "frac_at_measured_clock": r["valu_rate"] / (N_SIMD * prof["clock_ghz"] / 2.0),
                               "instr_per_ray": prof["valu_per_ray"], "lane_utilisation": prof["lane_utilisation"],
                               "lane_utilisation_note": "exec-mask utilisation (SQ_THREAD_CYCLES_VALU / 64 SQ_INSTS_VALU)",
                               "salu_per_valu": prof["salu_per_ray"] / prof["valu_per_ray"]}
                 # the scalar unit: one per CU, one instruction per cycle, shared by the CU's four SIMDs
-                salu_rate = prof["salu_per_ray"] * rays_per_launch / sec_per_launch / 1e9
-                rf["scalar"] = {"achieved": salu_rate, "peak": N_CU * MAX_CLOCK_GHZ, "unit": "G instr/s",
-                                "frac": salu_rate / (N_CU * MAX_CLOCK_GHZ)}
-                rf["hbm"] = {"achieved": hbm_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                rf["scalar"] = {"achieved": r["salu_rate"], "peak": N_CU * MAX_CLOCK_GHZ, "unit": "G instr/s", "frac": r["salu_frac"],
+                                "instr_per_ray": prof["salu_per_ray"]}
+                rf["hbm"] = {"achieved": r["hbm_rate"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["hbm_frac"],
                              "bytes_per_ray": prof["hbm_bytes_per_ray"], "l2_hit_rate": prof["l2_hit_rate"]}
+                pl, _ = roofline_from_profile(PIPE_KERNEL[pipe], workload, rays_per_launch, sec_per_launch)
+                rf["per_launch"] = {"avg_launch_ms": kernel_ms / launches, "valu_frac": pl["valu_frac"], "hbm_frac": pl["hbm_frac"],
+                                    "hbm_gbs": pl["hbm_rate"],
+                                    "note": "HIP-event duration of each launch on its own stream; two launches are in flight at a time, so "
+                                            "this is not the chip's rate (the timed-region figures above are)"}
+                if serial_ms:
+                    sr, _ = roofline_from_profile(PIPE_KERNEL[pipe], workload, rays_local / args.steps, serial_ms * 1e-3)
+                    rf["serial_render"] = {"ms": serial_ms, "valu_frac": sr["valu_frac"], "hbm_frac": sr["hbm_frac"],
+                                           "note": "one render at a time (no overlap of consecutive steps), whole mpt_render incl. resolve"}
                 rf["wave_cycles_split"] = prof["wave_cycles_split"]
                 rf["profile"] = {"file": prof["file"], "build": prof["build"], "workload": workload}
                 rf["source"] = ("%s (rocprofv3 --pmc, one counter set per pass, same build / scene / size / spp / knobs — checked by "
-                                "sha256: per-ray counters x this run's rays per launch / this run's HIP-event launch time; the "
-                                "profiled launch took %.2f ms)" % (prof["file"], prof["profiled_kernel_ms"]))
+                                "sha256; the profiled launch took %.2f ms)" % (prof["file"], prof["profiled_kernel_ms"]))
             else:
                 rf.update(bound="valu", achieved=None, peak=N_SIMD * MAX_CLOCK_GHZ / 2.0, unit="G wave64-instr/s", frac=None, traffic=None,
                           source="no usable counter profile: %s" % json.dumps(why), **why)

@@ -232,7 +232,24 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
             F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
             F3 h = cross3(d, e2);
             float a = dot3(e1, h);
+#ifdef MPT_WL_TRI_FLAT
+            // (experiment) without early-outs, as ot_test_prim in mpt_ordered.h: the same operations give the same values; where the
+            // reference leaves early the rest is computed from garbage and discarded by `hit`
+            {
+                const float f = 1.0f / a;
+                const F3 s = o - v0;
+                const float u = f * dot3(s, h);
+                const F3 q = cross3(s, e1);
+                const float v = f * dot3(d, q);
+                const float tt = f * dot3(e2, q);
+                const bool hit = fabsf(a) > 1e-5f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && tt > 0.0001f && tt < best_t;
+                best_t = hit ? tt : best_t;
+                best_prim = hit ? (int)(first + k) : best_prim;
+            }
+            if (false) {
+#else
             if (fabsf(a) > 1e-5f) {
+#endif
                 float f = 1.0f / a;
                 F3 s = o - v0;
                 float u = f * dot3(s, h);

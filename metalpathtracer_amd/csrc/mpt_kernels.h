@@ -674,8 +674,14 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             if (level == (int)MPT_WL_LEVELS && assigned >= 12u) min_active = assigned / 3u;
             if (take) {
                 const uint32_t at = wbase + my_ring * MPT_WL_RING + my_off;
+#ifdef MPT_WL_NT_POP   // (experiment) a ring record is read once: non-temporal pops
+                const float4 a = load_slot(ring.od, at), b = load_slot(ring.dt, at), cc = load_slot(ring.tl, at);
+                const float4 iaf = load_slot((const float4*)ring.ia, at);
+                const uint4 ia = make_uint4(__float_as_uint(iaf.x), __float_as_uint(iaf.y), __float_as_uint(iaf.z), __float_as_uint(iaf.w));
+#else
                 const float4 a = ring.od[at], b = ring.dt[at], cc = ring.tl[at];
                 const uint4 ia = ring.ia[at];
+#endif
                 ps.o = f3(a.x, a.y, a.z);
                 ps.d = f3(a.w, b.x, b.y);
                 ps.thr = f3(b.z, b.w, cc.x);

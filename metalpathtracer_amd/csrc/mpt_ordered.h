@@ -58,7 +58,15 @@
 #ifndef MPT_OT_MLEVELS
 #define MPT_OT_MLEVELS 2u                 // tree-walk rings: rays sorted by the walk they have already done (budgets).
 #endif                                    // bunny x20, 256 spp: 2 rings 76.8 ms, 3 rings 77.9, 4 rings 82.4
-#define MPT_OT_RINGS (2u + MPT_OT_MLEVELS) // R fresh rays, E reference-order walk, M0.. rays walking the tree
+// Ring R (fresh bounce rays) as EIGHT rings keyed by the direction octant (sign bits of d): the rays of a step then share
+// the order in which they visit a node's children, and — the rings of a wave are fed by consecutive samples of one 8x8 pixel
+// tile — origins that lie close together: the walks of a step look alike, which is what the node loop's lane utilisation and
+// the vector L1 want (DESIGN.md 5 "Round 4").  0 = one ring (round 3's kernel).
+#ifndef MPT_OT_OCT
+#define MPT_OT_OCT 1
+#endif
+#define MPT_OT_NR (MPT_OT_OCT ? 8u : 1u)  // fresh-ray rings
+#define MPT_OT_RINGS (MPT_OT_NR + 1u + MPT_OT_MLEVELS) // R (x NR) fresh rays, E reference-order walk, M0.. rays walking the tree
 #define MPT_OT_PARK 8u                    // stack entries a parked ray takes along (>= the LDS stack depth)
 #ifndef MPT_OT_EARLY
 #define MPT_OT_EARLY 2u                   // the node loop pauses when fewer than 1/EARLY of the lanes that entered it still search
@@ -515,10 +523,29 @@ __device__ __forceinline__ OtStack ot_stack(const AccelDev& ac, float4* lds_raw,
     return st;
 }
 
+// A ring record is read once: -DMPT_OT_NT_POP makes the pops non-temporal loads, so that they do not displace nodes and
+// primitives from the vector L1 (the walk is bound by its tag look-ups and misses).
+__device__ __forceinline__ float4 ot_pop4(const float4* p) {
+#ifdef MPT_OT_NT_POP
+    const v4f_nt v = __builtin_nontemporal_load((const v4f_nt*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint4 ot_pop4u(const uint4* p) {
+    const float4 v = ot_pop4((const float4*)p);
+    return make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+}
+
 // ---- the pipeline kernel ------------------------------------------------------------------------------------------
-#define MPT_OT_RING_R 0u
-#define MPT_OT_RING_E 1u
-#define MPT_OT_RING_M 2u       // M0 ... M(MLEVELS-1)
+#define MPT_OT_RING_R 0u                  // R0 ... R(NR-1)
+#define MPT_OT_RING_E MPT_OT_NR
+#define MPT_OT_RING_M (MPT_OT_NR + 1u)    // M0 ... M(MLEVELS-1)
+// A primary step adds up to 64 rays and runs only while no ring holds a full wave; with NR + 1 + MLEVELS rings of < 64 rays each
+// that alone no longer bounds the rays a wave has in flight by a ring's 512 records, so a primary step also needs the total to
+// leave room (the fullest fresh-ray ring runs a partial step otherwise).
+#define MPT_OT_MAX_INFLIGHT (MPT_WL_RING - 64u)
 #define MPT_OT_NONE 0xFFu
 
 template <bool COUNT, bool ALL_LDS>
@@ -547,7 +574,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
     uint32_t n_rays = 0, n_paths = 0, n_flagged = 0, n_parked = 0;
     WorkCount wc = {};
 #ifdef MPT_OT_TIMES
-    unsigned long long ot_acc[OT_NREG] = {}, ot_steps[MPT_OT_RINGS + 1] = {}, ot_lanes[MPT_OT_RINGS + 1] = {};
+    unsigned long long ot_acc[OT_NREG] = {}, ot_steps[8] = {}, ot_lanes[8] = {};   // slots: R (all octants), E, M0.., primary last
 #endif
     for (;;) {
         OT_TIC();
@@ -557,7 +584,16 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
 #pragma unroll
         for (int k = (int)MPT_OT_RINGS - 1; k >= (int)MPT_OT_RING_M; --k)  // the longest walks first
             if (kind == MPT_OT_NONE && cnt[k] >= 64u) kind = (uint32_t)k;
-        if (kind == MPT_OT_NONE && cnt[MPT_OT_RING_R] >= 64u) kind = MPT_OT_RING_R;
+        uint32_t r_best = MPT_OT_RING_R, r_fill = 0u, in_flight = 0u;   // the fullest fresh-ray ring
+#pragma unroll
+        for (uint32_t k = 0; k < MPT_OT_RINGS; ++k) {
+            in_flight += cnt[k];
+            if (k < MPT_OT_RING_E && cnt[k] > r_fill) {
+                r_fill = cnt[k];
+                r_best = k;
+            }
+        }
+        if (kind == MPT_OT_NONE && (r_fill >= 64u || (MPT_OT_NR > 1u && in_flight > MPT_OT_MAX_INFLIGHT && r_fill != 0u))) kind = r_best;
         if (kind == MPT_OT_NONE) {
             if (!exhausted && cur == end) {  // guided self-scheduling of path ids, as k_wavelocal (mpt_kernels.h)
                 uint32_t k = 0, blk = 0, rend = 0;
@@ -597,7 +633,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 for (int k = (int)MPT_OT_RINGS - 1; k >= (int)MPT_OT_RING_M; --k)
                     if (kind == MPT_OT_NONE && cnt[k] != 0u) kind = (uint32_t)k;
                 if (kind == MPT_OT_NONE) {
-                    if (cnt[MPT_OT_RING_R] != 0u) kind = MPT_OT_RING_R;
+                    if (r_fill != 0u) kind = r_best;
                     else if (cnt[MPT_OT_RING_E] != 0u) kind = MPT_OT_RING_E;
                     else break;
                 }
@@ -648,13 +684,13 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             for (uint32_t k = 0; k < MPT_OT_RINGS; ++k)
                 if (k == kind) cnt[k] = c - take;
             if (valid) {
-                const float4 a = ring.od[at], b = ring.dt[at];
+                const float4 a = ot_pop4(ring.od + at), b = ot_pop4(ring.dt + at);
                 ps.o = f3(a.x, a.y, a.z);
                 ps.d = f3(a.w, b.x, b.y);
                 ps.thr.x = b.z;
                 ps.thr.y = b.w;
                 if (kind >= MPT_OT_RING_M) {
-                    const uint4 tv = ring.tv[at];
+                    const uint4 tv = ot_pop4u(ring.tv + at);
                     T = __uint_as_float(tv.x);
                     W = (int)tv.y;
                     walk_cur = tv.z;
@@ -670,7 +706,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
                     if (2u * k >= deepest) break;
                     if (valid && walk_sp > 2u * k) {
-                        const uint4 e = ring.sk[k][at];
+                        const uint4 e = ot_pop4u(ring.sk[k] + at);
                         st.lds[(2u * k) * 64u] = v2u{e.x, e.y};
                         st.lds[(2u * k + 1u) * 64u] = v2u{e.z, e.w};
                     }
@@ -679,8 +715,8 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         }
         // the rest of a record is not needed by the tree walk: ring M steps load it afterwards
         auto load_rest = [&]() {
-            const float4 cc = ring.tl[at];
-            const uint4 ia = ring.ia[at];
+            const float4 cc = ot_pop4(ring.tl + at);
+            const uint4 ia = ot_pop4u(ring.ia + at);
             ps.thr.z = cc.x;
             ps.L = f3(cc.y, cc.z, cc.w);
             ps.La = __uint_as_float(ia.y);
@@ -694,15 +730,16 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         if (valid && kind != MPT_OT_NONE && kind < MPT_OT_RING_M) load_rest();
         OT_TOC(1);
 #ifdef MPT_OT_TIMES
-        ot_steps[kind == MPT_OT_NONE ? MPT_OT_RINGS : kind] += 1;
-        ot_lanes[kind == MPT_OT_NONE ? MPT_OT_RINGS : kind] += (unsigned long long)__popcll(__ballot(valid));
+        const uint32_t ot_slot = kind == MPT_OT_NONE ? 2u + MPT_OT_MLEVELS : kind < MPT_OT_RING_E ? 0u : kind - MPT_OT_RING_E + 1u;
+        ot_steps[ot_slot] += 1;
+        ot_lanes[ot_slot] += (unsigned long long)__popcll(__ballot(valid));
 #endif
         uint32_t dest = MPT_OT_NONE;      // ring this lane's ray goes to next
         bool shade = false;               // ... or its closest hit is final: one bounce of shading now
         uint32_t walk_kind = MPT_OT_NONE; // wave-uniform: the step walks the tree with this ring's budget
         bool walking = false;             // ... and this lane takes part
         const OtRay r = ot_ray(ps.o, ps.d);
-        if (kind == MPT_OT_NONE || kind == MPT_OT_RING_R) {
+        if (kind == MPT_OT_NONE || kind < MPT_OT_RING_E) {
             // ---- TOP TEST: always-list spheres + the root's boxes ------------------------------------------------------
             if (valid) {
                 bool tie = false, need = false;
@@ -781,7 +818,8 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         // ---- one bounce of shading for the rays whose closest hit is final ----------------------------------------------
         if (shade) {
             n_rays++;
-            if (shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W)) dest = MPT_OT_RING_R;
+            if (shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W))
+                dest = MPT_OT_RING_R + (MPT_OT_NR > 1u ? (ps.d.x < 0.0f ? 1u : 0u) | (ps.d.y < 0.0f ? 2u : 0u) | (ps.d.z < 0.0f ? 4u : 0u) : 0u);
             else store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
         }
         n_flagged += dest == MPT_OT_RING_E ? 1u : 0u;
@@ -828,7 +866,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
     ot_flush_walk_times(wc, lane);
     if (lane == 0) {
         for (int k = 0; k < OT_NREG; ++k) atomicAdd(&g_ot_times[k], ot_acc[k]);
-        for (int k = 0; k <= (int)MPT_OT_RINGS; ++k) {
+        for (int k = 0; k <= (int)(2u + MPT_OT_MLEVELS); ++k) {
             atomicAdd(&g_ot_times[OT_NREG + k], ot_steps[k]);
             atomicAdd(&g_ot_times[OT_NREG + 8 + k], ot_lanes[k]);
         }

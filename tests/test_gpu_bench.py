@@ -39,6 +39,13 @@ def test_bench_line_single_gpu():
         assert rf["valu"]["peak"] == 1024 * 2.4 / 2 and rf["valu"]["frac_at_measured_clock"] >= rf["valu"]["frac"]
         assert rf["hbm"]["peak"] == 8000.0 and 0.0 < rf["valu"]["lane_utilisation"] <= 1.0
         assert rf["traffic"] > 0 and "profiles/" in rf["source"]
+        # THE fraction is achieved-over-the-timed-region: per-ray counters x the rays of the K timed steps / their wall time —
+        # the same clock `value` is quoted on — not the (overlapped, longer) HIP-event duration of a single launch
+        wall_s = d["ms_per_step"] * d["steps"] * 1e-3
+        assert abs(rf["valu"]["frac"] - rf["valu"]["instr_per_ray"] * d["config"]["rays"] / wall_s / 1e9 / rf["valu"]["peak"]) < 1e-6 * rf["valu"]["frac"] + 1e-12
+        assert abs(rf["hbm"]["achieved"] - rf["hbm"]["bytes_per_ray"] * d["config"]["rays"] / wall_s / 1e9) < 1e-6 * rf["hbm"]["achieved"] + 1e-9
+        assert rf["per_launch"]["avg_launch_ms"] == rf["avg_launch_ms"] and 0.0 < rf["per_launch"]["valu_frac"] <= 1.0
+        assert 0.0 < rf["serial_render"]["valu_frac"] <= 1.0
         from metalpathtracer_amd import capi
         bid, pb = capi.build_id(), rf["profile"]["build"]
         assert pb["source_sha256"] == bid["source_sha256"] or pb["lib_sha256"] == bid["lib_sha256"]
@@ -49,11 +56,19 @@ def test_bench_line_single_gpu():
     assert d["serial_ms_per_render"] > 0 and d["config"]["serial_mrays_per_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
+    assert "device-built tree" in cb["tree"] and cb["reference_tree"]["value"] > 0      # which tree the CPU leg walked, and the reference's own
     assert d["config"]["paths"] == 640 * 360 * 8 * 2
-    ex = d["extra_workloads"]       # untimed extras: the Cornell-style scene and bunny x20 at 1920x1080 x 256 spp, one serial render each
-    assert [e["workload"].split()[0] for e in ex] == ["cornell.xml", "bunny20.xml"]
-    assert all(e["ms_per_render"] > 0 and e["mrays_per_s"] > 0 and e["paths"] == 1920 * 1080 * 256 for e in ex)
-    assert "closest-first" in ex[1]["pipeline"] and "reference-order" in ex[0]["pipeline"]
+    # untimed extras, one serial render each: the Cornell-style scene and bunny x20 (device-built trees), scene.xml on the REFERENCE's
+    # own tree, and configs[4] at its real size (1/8 tile shard, 4096 spp, depth 16, Scatter.h BSDFs)
+    ex = d["extra_workloads"]
+    assert [e["workload"].split()[0] for e in ex] == ["cornell.xml", "bunny20.xml", "scene.xml", "config4"]
+    assert all(e["ms_per_render"] > 0 and e["mrays_per_s"] > 0 for e in ex)
+    assert all(e["paths"] == 1920 * 1080 * 256 for e in ex[:3]) and ex[3]["paths"] == 4050 * 64 * 4096 and ex[3]["prims"] == 1000003
+    assert "closest-first" in ex[1]["pipeline"] and "reference-order" in ex[0]["pipeline"] and "closest-first" in ex[3]["pipeline"]
+    assert ex[2]["bvh_builder"] == "reference" and "reference-order" in ex[2]["pipeline"]
+    for e in ex:                    # each extra names its own counter profile, or says that none of this build is committed
+        r = e["roofline"]
+        assert (r["frac"] is not None and 0.0 < r["frac"] <= 1.0 and "profiles/" in r["profile"]) or r.get("profile_stale") is True or "profile_missing" in r
 
 
 def test_bench_two_ranks_share_the_gpu_and_agree_with_one_rank():

@@ -20,8 +20,9 @@ i=0
 for SET in "${SETS[@]}"; do
   i=$((i+1)); D=$OUT/pmc_${TAG}_$i; rm -rf $D
   cd /tmp && export TMPDIR=/tmp
-  timeout -k 5 240 rocprofv3 --pmc $SET --output-format csv -d $D -o s -- python3 $ROOT/tools/prof_run.py > $D.log 2>&1 \
-    || echo "set $i failed: $(grep -m1 -i 'error\|exceeds' $D.log | cut -c1-200)"
+  if ! timeout -k 5 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $SET --output-format csv -d $D -o s -- python3 $ROOT/tools/prof_run.py > $D.log 2>&1; then
+    echo "set $i ($SET) FAILED: $(grep -m1 -i 'error\|exceeds\|signal' $D.log | cut -c1-200)"; exit 1
+  fi
   cd $ROOT
   dirs="$dirs $D"
   grep -h "Mrays" $D.log | tail -1
