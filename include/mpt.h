@@ -242,7 +242,8 @@ int mpt_gpu_leaf_max(uint64_t n_prims);
 /* What the last scene call left on the device: out[0] = primitives of the tree mpt_download_bvh would return (0 when the scene
  * came through mpt_upload_scene: MPT_ERR_NOT_READY there), [1] nodes of that tree, [2] the leaf limit it was built with,
  * [3] MPT_AUTO_ORDERED_PRIMS (the scene size from which MPT_PIPE_AUTO means the closest-first pipeline), [4] primitives of the
- * uploaded scene, [5] threaded reference-order nodes, [6] de-duplicated materials, [7] 0.                                   */
+ * uploaded scene, [5] threaded reference-order nodes, [6] de-duplicated materials, [7] nodes of the own 4-wide tree that the
+ * closest-first walk fetches in their float form because their boxes could not be quantised (degenerate input; normally 0).  */
 int mpt_build_info(mpt_ctx* ctx, uint64_t out[8]);
 
 /* ---- multi-GPU: tile shards + ONE RCCL reduce of the HDR sum over xGMI ---------------------------------

@@ -381,7 +381,7 @@ class Context:
         """mpt_build_info: what the last scene call left on the device (sizes come from the C API, not from this object)."""
         out = (C.c_uint64 * 8)()
         self._chk(self.L.mpt_build_info(self.h, out), "mpt_build_info")
-        keys = ("built_prims", "built_nodes", "built_leaf_max", "auto_ordered_prims", "prims", "threaded_nodes", "materials")
+        keys = ("built_prims", "built_nodes", "built_leaf_max", "auto_ordered_prims", "prims", "threaded_nodes", "materials", "unquantised_nodes")
         return dict(zip(keys, [int(v) for v in out]))
 
     def download_bvh(self):

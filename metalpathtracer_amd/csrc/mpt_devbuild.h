@@ -437,7 +437,7 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
         uint32_t* p = nullptr;
         ~Pinned() { if (p) hipHostFree(p); }
     } pinned;
-    MPT_LB(hipHostMalloc((void**)&pinned.p, 256, hipHostMallocDefault));
+    MPT_LB(hipHostMalloc((void**)&pinned.p, 1024, hipHostMallocDefault));   // (words 64.. : the level slots of mpt_sah::run_sah)
     uint32_t* pin = pinned.p;
     MPT_LB(sc.alloc(&d_sc, 1));
     MPT_LB(hipMemsetAsync(d_sc, 0, sizeof(Scalars), stream));

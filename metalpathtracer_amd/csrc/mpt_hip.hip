@@ -103,6 +103,8 @@ struct mpt_ctx {
     bool have_scene = false;
     // the product's own tree (mpt_accel.h) for the closest-first pipeline; it shares d_prims with the threaded tree
     float4* d_acc_nodes = nullptr;
+    float4* d_acc_qnodes = nullptr;   // the same nodes in the 64-byte form the walk fetches from global memory (mpt_ordered.h)
+    uint32_t n_acc_float = 0;         // ... of which so many could not be quantised and are fetched as floats (degenerate boxes)
     float4* d_refleaf = nullptr;
     float4* d_always = nullptr;
     uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, ot_lds_nodes = 0, ot_lds_prims = 0;
@@ -335,6 +337,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_prims);
     hipFree(ctx->d_mats);
     hipFree(ctx->d_acc_nodes);
+    hipFree(ctx->d_acc_qnodes);
     hipFree(ctx->d_refleaf);
     hipFree(ctx->d_always);
     hipFree(ctx->d_ref_bvh);
@@ -415,6 +418,28 @@ static void size_lds_images(mpt_ctx* ctx) {
         if (const char* e = getenv("MPT_OT_LDS_PRIMS")) ctx->ot_lds_prims = std::min<uint32_t>(ctx->ot_lds_prims, (uint32_t)atoi(e));
         ctx->ot_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
     }
+}
+
+// The 64-byte form of the own tree's nodes (k_quantize_nodes, mpt_ordered.h): derived on the device from the float nodes, whichever
+// route made them.
+static int quantize_acc_nodes(mpt_ctx* ctx) {
+    hipFree(ctx->d_acc_qnodes);
+    ctx->d_acc_qnodes = nullptr;
+    ctx->n_acc_float = 0;
+    if (!MPT_OT_QNODES) return MPT_OK;   // (the experiment is compiled out: no second copy of the nodes)
+    const uint32_t n = std::max(ctx->n_acc_nodes, 1u);
+    ctx->n_acc_float = 0;
+    HIPCHK(hipMalloc(&ctx->d_acc_qnodes, (size_t)n * 64 + 64));   // (+ the counter of nodes left as floats, behind the nodes)
+    uint32_t* d_count = (uint32_t*)(ctx->d_acc_qnodes + 4u * (size_t)n);
+    HIPCHK(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+    if (ctx->n_acc_nodes) {
+        hipLaunchKernelGGL(k_quantize_nodes, dim3((ctx->n_acc_nodes + 255u) / 256u), dim3(256), 0, ctx->stream, (const float4*)ctx->d_acc_nodes, ctx->n_acc_nodes,
+                           ctx->d_acc_qnodes, d_count);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&ctx->n_acc_float, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return MPT_OK;
 }
 
 static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims,
@@ -744,6 +769,10 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     ctx->n_prims = (uint32_t)(dprims.size() / 12);
     ctx->n_mats = (uint32_t)(mat_table.size() / 8);
     ctx->n_acc_nodes = (uint32_t)(acc_nodes.size() / MPT_ACCEL_NODE_FLOATS);
+    {
+        int qrc = quantize_acc_nodes(ctx);
+        if (qrc) return qrc;
+    }
     ctx->n_always = (uint32_t)(always.size() / 20);
     ctx->n_ref_leaves = (uint32_t)(refleaf.size() / 8);
     ctx->acc_depth = topo.depth;
@@ -875,6 +904,7 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     s.n_lds_nodes = 0;
     s.n_lds_prims = ctx->ot_lds_prims;
     a.nodes = ctx->d_acc_nodes;
+    a.qnodes = ctx->d_acc_qnodes;
     a.refleaf = ctx->d_refleaf;
     a.always = ctx->d_always;
     a.n_nodes = ctx->n_acc_nodes;
@@ -1593,6 +1623,11 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     ctx->d_prims = b.prims;
     ctx->d_mats = b.mats;
     ctx->d_acc_nodes = b.acc_nodes;
+    ctx->n_acc_nodes = b.n_acc_nodes;
+    {
+        int qrc = quantize_acc_nodes(ctx);
+        if (qrc) return qrc;
+    }
     ctx->d_refleaf = b.refleaf;
     ctx->d_always = b.always;
     ctx->d_ref_bvh = b.ref_bvh;
@@ -1711,7 +1746,7 @@ extern "C" int mpt_build_info(mpt_ctx* ctx, uint64_t out[8]) {
     if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
     const bool built = ctx->d_ref_bvh != nullptr;
     const uint64_t v[8] = {built ? ctx->n_prims : 0u, built ? ctx->n_ref_nodes : 0u, built ? ctx->built_leaf_max : 0u, MPT_AUTO_ORDERED_PRIMS,
-                           ctx->n_prims, ctx->n_nodes, ctx->n_mats, 0u};
+                           ctx->n_prims, ctx->n_nodes, ctx->n_mats, ctx->n_acc_float};
     memcpy(out, v, sizeof v);
     return MPT_OK;
 }

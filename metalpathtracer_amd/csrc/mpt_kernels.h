@@ -414,7 +414,13 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams p
 // Result slots are written once and read once, much later, by the resolve kernel: streaming (non-temporal) accesses
 // keep them from evicting the ring records the trace kernel is about to pop.
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
+// Traffic experiments (round 4, DESIGN.md 8 "the traffic diet"): -DMPT_DIET_NOSLOT drops the slot store (WRONG image: the upper
+// bound of what any slot diet can win), -DMPT_DIET_RINGPLUS writes one more 16-byte word per push to ring 0, 25 % more ring traffic (what ring traffic costs).
 __device__ __forceinline__ void store_slot(float4* slots, uint32_t path, float r, float g, float b, float a) {
+#ifdef MPT_DIET_NOSLOT
+    if (r == 12345.678f) slots[path] = make_float4(r, g, b, a);   // (never true for a clamped colour: the store is compiled, not executed)
+    return;
+#endif
 #ifdef MPT_SLOTS_TEMPORAL
     slots[path] = make_float4(r, g, b, a);
 #else
@@ -463,13 +469,74 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 #define MPT_WL_RING 512u       // records per ring
 #define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
 #define MPT_WL_NO_BUDGET 0x7FFFFFFFu  // budgets at or above this mean "run to completion"
+// Ring record (round 4, "the traffic diet"): 48 bytes that every ray needs — od, dt, ia — and 16 more (tl: the light gathered so
+// far) only for the rays that HAVE gathered light: L and alpha are all-zero bits until a path meets an emitter, which most bounce
+// rays of most scenes never have (a flag in ia says whether tl was written; the pop restores exact zeros otherwise).  The sample
+// index is recomputed from the path id.  Measured before building it (MPT_DIET_RINGPLUS / MPT_DIET_NOSLOT builds, in-kernel
+// clock stamped): 16 bytes MORE per push cost 3.0 % (19.23 -> 19.81 ms, clock 2.243 -> 2.203 GHz), dropping the result slots
+// altogether — the bound of any slot diet — gains 3.2 %.  -DMPT_WL_DIET=0 is round 3's 64-byte record.
+#ifndef MPT_WL_DIET
+#define MPT_WL_DIET 1
+#endif
+#define MPT_RING_HAS_LIGHT 0x100u
 struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING]
     float4* od;                // (o.xyz, d.x)
     float4* dt;                // (d.y, d.z, thr.r, thr.g)
-    float4* tl;                // (thr.b, L.rgb)
-    uint4* ia;                 // (path, L.a bits, pixel, sample | bounce << 27)   path ids use all 32 bits here
+    float4* tl;                // MPT_WL_DIET: (L.rgb, L.a), written only with MPT_RING_HAS_LIGHT; else (thr.b, L.rgb)
+    uint4* ia;                 // MPT_WL_DIET: (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT); else (path, L.a bits, pixel, sample | bounce << 27)
     uint4* tv;                 // rings >= 1: (next node, best t bits, best primitive, 0)
 };
+// what a push writes / a pop reads (both pipelines' rings use the same record)
+__device__ __forceinline__ bool ring_has_light(const PathState& ps) {
+    return (__float_as_uint(ps.L.x) | __float_as_uint(ps.L.y) | __float_as_uint(ps.L.z) | __float_as_uint(ps.La)) != 0u;
+}
+__device__ __forceinline__ uint32_t sample_of_path(const PassParams& pp, uint32_t path) {
+    const uint32_t chunk = path >> 6;
+    return pp.sample_begin + (pp.s_shift != 0xFFu ? chunk & (pp.S - 1u) : chunk % pp.S);
+}
+__device__ __forceinline__ void ring_push(const WaveRings& ring, uint32_t at, const PathState& ps, const PathRngDev& g) {
+    ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+#if MPT_WL_DIET
+    const bool lit = ring_has_light(ps);
+    ring.ia[at] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
+    if (lit) ring.tl[at] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
+#else
+    ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+    ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+#endif
+}
+__device__ __forceinline__ void ring_pop(const PassParams& pp, const WaveRings& ring, uint32_t at, PathState& ps, PathRngDev& g) {
+    const float4 a = ring.od[at], b = ring.dt[at];
+    const uint4 ia = ring.ia[at];
+    ps.o = f3(a.x, a.y, a.z);
+    ps.d = f3(a.w, b.x, b.y);
+#if MPT_WL_DIET
+    ps.thr = f3(b.z, b.w, __uint_as_float(ia.x));
+    ps.path = ia.y;
+    g.pixel = ia.z;
+    ps.bounce = ia.w & 0xFFu;
+    g.sample = sample_of_path(pp, ps.path);
+    ps.L = f3(0.0f, 0.0f, 0.0f);
+    ps.La = 0.0f;
+    if ((ia.w & MPT_RING_HAS_LIGHT) != 0u) {
+        const float4 cc = ring.tl[at];
+        ps.L = f3(cc.x, cc.y, cc.z);
+        ps.La = cc.w;
+    }
+#else
+    const float4 cc = ring.tl[at];
+    ps.thr = f3(b.z, b.w, cc.x);
+    ps.L = f3(cc.y, cc.z, cc.w);
+    ps.La = __uint_as_float(ia.y);
+    ps.path = ia.x;
+    ps.bounce = ia.w >> 27;
+    g.pixel = ia.z;
+    g.sample = ia.w & 0x07FFFFFFu;
+#endif
+    g.lit_seed = 0;
+    if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+}
 struct WaveBudgets {
     uint32_t b[MPT_WL_LEVELS]; // box-test loop trips granted per step of ring k (last entry unused: unlimited)
     uint32_t min_active[MPT_WL_LEVELS];  // a step of ring k ends early once fewer lanes than this are still traversing
@@ -674,27 +741,10 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             if (level == (int)MPT_WL_LEVELS && assigned >= 12u) min_active = assigned / 3u;
             if (take) {
                 const uint32_t at = wbase + my_ring * MPT_WL_RING + my_off;
-#ifdef MPT_WL_NT_POP   // (experiment) a ring record is read once: non-temporal pops
-                const float4 a = load_slot(ring.od, at), b = load_slot(ring.dt, at), cc = load_slot(ring.tl, at);
-                const float4 iaf = load_slot((const float4*)ring.ia, at);
-                const uint4 ia = make_uint4(__float_as_uint(iaf.x), __float_as_uint(iaf.y), __float_as_uint(iaf.z), __float_as_uint(iaf.w));
-#else
-                const float4 a = ring.od[at], b = ring.dt[at], cc = ring.tl[at];
-                const uint4 ia = ring.ia[at];
-#endif
-                ps.o = f3(a.x, a.y, a.z);
-                ps.d = f3(a.w, b.x, b.y);
-                ps.thr = f3(b.z, b.w, cc.x);
-                ps.L = f3(cc.y, cc.z, cc.w);
-                ps.La = __uint_as_float(ia.y);
-                ps.path = ia.x;
-                ps.bounce = ia.w >> 27;
-                g.pixel = ia.z;
-                g.sample = ia.w & 0x07FFFFFFu;
-                g.lit_seed = 0;
-                if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+                uint4 tv = make_uint4(0u, 0u, 0u, 0u);
+                if (my_ring > 0u) tv = ring.tv[at];   // (issued with the record's other loads, ahead of ring_pop's conditional one)
+                ring_pop(pp, ring, at, ps, g);
                 if (my_ring > 0u) {
-                    const uint4 tv = ring.tv[at];
                     node = tv.x;
                     best_t = __uint_as_float(tv.y);
                     best_prim = (int)tv.z;
@@ -752,10 +802,10 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         if (am != 0ull) {  // survivors are fresh rays -> ring 0
             if (alive) {
                 const uint32_t at = wbase + ((head[0] + cnt[0] + wave_rank(am)) & M);
-                ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-                ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+                ring_push(ring, at, ps, g);
+#ifdef MPT_DIET_RINGPLUS   // (ring.tv of ring 0 is never read: fresh rays carry no traversal state)
+                ring.tv[at] = make_uint4(ps.path, 0u, 0u, 0u);
+#endif
             }
             cnt[0] += (uint32_t)__popcll(am);
         }
@@ -769,10 +819,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 }
             if (parked) {
                 const uint32_t at = wbase + (uint32_t)park_ring * MPT_WL_RING + ((h + c + wave_rank(pm)) & M);
-                ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-                ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+                ring_push(ring, at, ps, g);
                 ring.tv[at] = make_uint4(node, __float_as_uint(best_t), (uint32_t)best_prim, 0u);
             }
 #pragma unroll

@@ -403,11 +403,64 @@ __global__ void k_sah_to_radix(int n, const int2* s_child, const float4* s_lo, c
 // the triangles) than on the "optimal" tree, and the closest-first kernel keeps its spheres on a list anyway.  So when there
 // are 1..MPT_LBVH_HOIST_MAX spheres (and >= 3 triangles) the SAH runs over the triangles alone and the spheres hang under a new
 // root as a chain: ids 0 = the root, 1 .. ns-1 = the chain, ns + k = SAH node k.
+// Round 4: the same goes for ANY item whose box dwarfs the rest — a ground quad of two 10^4-unit triangles stretches the root box
+// exactly as the ground sphere does.  An item is "huge" when the binary exponent of its box's largest extent is >= 11 above
+// the MEDIAN item's (>= 2^10 x the median extent, by binades: a 256-bin histogram of the exponents, no sort); up to
+// MPT_LBVH_HOIST_MAX spheres + huge triangles hang under the root (if there are more, the spheres alone do, as before).
 #define MPT_LBVH_HOIST_MAX 16u
-__global__ void k_tri_flags(int n, const float4* prims, uint32_t* flag) {
+#define MPT_LBVH_HUGE_BINADES 11
+struct HoistState {
+    uint32_t hist[256];   // exponent of the largest box extent, per item
+    uint32_t n_sph, n_huge, mode, thresh;   // mode: 0 nothing hangs under the root, 1 the spheres, 2 spheres and huge triangles; thresh: exponent from which a box is huge
+};
+__device__ __forceinline__ uint32_t box_exponent(float4 l, float4 h) {
+    const float e = fmaxf(fmaxf(h.x - l.x, h.y - l.y), h.z - l.z);
+    return e > 0.0f && e < INFINITY ? (__float_as_uint(e) >> 23) & 255u : 0u;   // (empty, NaN and infinite boxes: bin 0, never huge)
+}
+__global__ void k_hoist_hist(int n, const float4* prims, const float4* blo, const float4* bhi, HoistState* st) {
+    __shared__ uint32_t h[256];
+    for (uint32_t q = threadIdx.x; q < 256u; q += blockDim.x) h[q] = 0u;
+    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) flag[p] = (int)prims[3 * (size_t)p].w == 1 ? 1u : 0u;
-    if (p == n) flag[n] = 0u;
+    bool sphere = false;
+    if (p < n) {
+        sphere = (int)prims[3 * (size_t)p].w != 1;
+        atomicAdd(&h[box_exponent(blo[p], bhi[p])], 1u);
+    }
+    const unsigned long long m = __ballot(sphere);
+    if ((threadIdx.x & 63u) == 0u && m != 0ull) atomicAdd(&st->n_sph, (uint32_t)__popcll(m));
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < 256u; q += blockDim.x)
+        if (h[q]) atomicAdd(&st->hist[q], h[q]);
+}
+__global__ void k_hoist_median(int n, HoistState* st) {   // one thread: the median exponent -> the threshold
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0, med = 0;
+    for (uint32_t q = 0; q < 256u; ++q) {
+        run += st->hist[q];
+        if (2u * run >= (uint32_t)n) {
+            med = q;
+            break;
+        }
+    }
+    st->thresh = med == 0u ? 256u : med + MPT_LBVH_HUGE_BINADES;   // (median box empty or degenerate: nothing is huge)
+    uint32_t huge = 0;
+    for (uint32_t q = st->thresh; q < 256u; ++q) huge += st->hist[q];
+    st->n_huge = huge;   // (counts huge spheres too: an upper bound of the huge triangles, exact when the spheres are small)
+}
+// flag = 1: the item takes part in the SAH; 0: it hangs under the root
+__global__ void k_tri_flags(int n, const float4* prims, const float4* blo, const float4* bhi, HoistState* st, uint32_t* flag) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool with_huge = st->n_sph + st->n_huge <= MPT_LBVH_HOIST_MAX && st->n_huge != 0u;
+    if (p < n) {
+        const bool tri = (int)prims[3 * (size_t)p].w == 1;
+        const bool huge = with_huge && box_exponent(blo[p], bhi[p]) >= st->thresh;
+        flag[p] = tri && !huge ? 1u : 0u;
+    }
+    if (p == n) {
+        flag[n] = 0u;
+        st->mode = with_huge ? 2u : 1u;
+    }
 }
 __global__ void k_prim_items_hoisted(int n, const float4* blo, const float4* bhi, const uint32_t* flag, const uint32_t* rank, float4* it_lo, float4* it_hi,
                                      uint32_t* vals, uint32_t* sph) {
@@ -524,7 +577,7 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
         uint32_t* p = nullptr;
         ~Pinned() { if (p) hipHostFree(p); }
     } pinned;
-    MPT_LB(hipHostMalloc((void**)&pinned.p, 64, hipHostMallocDefault));
+    MPT_LB(hipHostMalloc((void**)&pinned.p, 1024, hipHostMallocDefault));   // (words 64.. : the level slots of mpt_sah::run_sah)
     const size_t nn = 2 * (size_t)n - 1;
     R.n = n;
     R.leaf_max = leaf_max;
@@ -565,10 +618,16 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
         MPT_LB(sc.alloc(&size, nn));
         MPT_LB(sc.alloc(&first, nn));
         uint32_t *flag, *rank, *sph;
+        HoistState* hoist;
         MPT_LB(sc.alloc(&flag, (size_t)n + 1));
         MPT_LB(sc.alloc(&rank, (size_t)n + 1));
         MPT_LB(sc.alloc(&sph, MPT_LBVH_HOIST_MAX));
-        hipLaunchKernelGGL(k_tri_flags, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, (int)n, (const float4*)d_prims, flag);
+        MPT_LB(sc.alloc(&hoist, 1));
+        MPT_LB(hipMemsetAsync(hoist, 0, sizeof(HoistState), stream));
+        hipLaunchKernelGGL(k_hoist_hist, dim3(gn), dim3(B), 0, stream, (int)n, (const float4*)d_prims, (const float4*)R.blo, (const float4*)R.bhi, hoist);
+        hipLaunchKernelGGL(k_hoist_median, dim3(1), dim3(64), 0, stream, (int)n, hoist);
+        hipLaunchKernelGGL(k_tri_flags, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, (int)n, (const float4*)d_prims, (const float4*)R.blo, (const float4*)R.bhi, hoist,
+                           flag);
         {
             size_t sb = 0;
             MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, flag, rank, (int)n + 1, stream));

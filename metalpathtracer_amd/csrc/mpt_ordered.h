@@ -61,9 +61,12 @@
 // Ring R (fresh bounce rays) as EIGHT rings keyed by the direction octant (sign bits of d): the rays of a step then share
 // the order in which they visit a node's children, and — the rings of a wave are fed by consecutive samples of one 8x8 pixel
 // tile — origins that lie close together: the walks of a step look alike, which is what the node loop's lane utilisation and
-// the vector L1 want (DESIGN.md 5 "Round 4").  0 = one ring (round 3's kernel).
+// the vector L1 want.  MEASURED AND REJECTED (round 4): bunny x20 71.4 ms against 64.3 with one ring, the 1 M-triangle
+// shard 148 against 133 — the rays of a wave wait in eight rings instead of one (four times the live records: more of them
+// fall out of the L2) and the steps gain nothing back: every lane still fetches its own node, so the octant does not lower
+// the tag look-ups per load instruction.  Kept behind the flag for the record; 0 = one ring (the product).
 #ifndef MPT_OT_OCT
-#define MPT_OT_OCT 1
+#define MPT_OT_OCT 0
 #endif
 #define MPT_OT_NR (MPT_OT_OCT ? 8u : 1u)  // fresh-ray rings
 #define MPT_OT_RINGS (MPT_OT_NR + 1u + MPT_OT_MLEVELS) // R (x NR) fresh rays, E reference-order walk, M0.. rays walking the tree
@@ -103,8 +106,8 @@ __device__ __forceinline__ void ot_flush_walk_times(const WorkCount& wc, uint32_
 struct OtRings {              // [n_waves][MPT_OT_RINGS][MPT_WL_RING] records, struct of arrays of 16-byte fields
     float4* od;               // (o.xyz, d.x)
     float4* dt;               // (d.y, d.z, thr.r, thr.g)
-    float4* tl;               // (thr.b, L.rgb)
-    uint4* ia;                // (path, L.a bits, pixel, sample | bounce << 27)
+    float4* tl;               // as WaveRings (mpt_kernels.h): with MPT_WL_DIET (L.rgb, L.a), written only for rays that have gathered light
+    uint4* ia;                // ... and (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT)
     uint4* tv;                // rings M, H: (best t bits, best primitive, next node / leaf of the walk, stack entries)
     uint4* sk[MPT_OT_PARK / 2u];  // rings M: the walk's stack, two (key, ref) entries per field
 };
@@ -114,8 +117,27 @@ struct OtBudgets {
     uint32_t inplace_min;                 // a primary / ring-R step whose top test sends at least this many lanes into the tree
 };                                        // walks it at once (as a ring-M0 step would) instead of parking them; 65 = never
 
+// Nodes that the walk fetches from GLOBAL memory come in a second, 64-byte form (round 4): the walk is bound by the tag
+// look-ups of the vector L1 — every lane fetches its own node, seven 16-byte loads each — and 64 bytes are four.  Measured
+// with a build that adds dummy loads of the same node (L1 hits): +3 loads per global node visit = +11.7 % on bunny x20, +7 =
+// +23.9 %; +30 vector instructions per node visit = +5.5 %.  Layout (k_quantize_nodes below):
+//   w0 = (o.x, o.y, o.z, s.x)   w1 = (s.y, s.z, bits(lo.x[4 x u8]), bits(lo.y[4]))   w2 = bits(lo.z[4], hi.x[4], hi.y[4], hi.z[4])   w3 = child[4]
+// child plane = fma(q, s, o) in fp32 — the quantiser VERIFIES with that very expression that every decoded box contains the
+// float box it stands for (lo planes rounded down, hi planes up), so nothing of the exactness argument above changes: the
+// boxes only grow (by < 1/255 of the node's extent per side).  A node with a plane that is not finite (degenerate input) or
+// an extent that overflows gets boxes that every ray enters (its children are then tested as always).  The nodes staged in
+// LDS stay floats (112 B).
+// MEASURED AND REJECTED (round 4): bunny x20 68.8 ms against 64.4 with float nodes, the 1 M-triangle shard 139.0 against 132.5,
+// scene.xml 23.2 against 22.5 — node visits +0.7 %, but the 57 vector instructions of the decode are paid by every trip in
+// which any lane is at a global node, and the three loads saved are worth less than the dummy-load experiment suggested
+// (those were hits under a pending miss of the same line).  A first version that tested one loaded word (an "unquantisable"
+// mark) before issuing the other loads cost a second round trip per visit: 72.6 ms.  Kept behind the flag; 0 = float nodes.
+#ifndef MPT_OT_QNODES
+#define MPT_OT_QNODES 0
+#endif
 struct AccelDev {
     const float4* nodes;    // MPT_OT_NODE_STRIDE float4 per node (7 used), breadth-first (mpt_accel.h)
+    const float4* qnodes;   // the same nodes, 4 float4 each (quantised child boxes)
     const float4* refleaf;  // 2 float4 per reference leaf: (bmin, 0) (bmax, 0)
     const float4* always;   // 5 float4 per sphere of the always list: (c, leaf<<1) (r, bits(index), bits(k), mat) (0,0,0, orig id)
                             // + the box of its reference leaf (bmin, 0) (bmax, 0)
@@ -181,6 +203,31 @@ __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds,
         nd.hz = make_float4(f.x, f.y, f.z, f.w);
         nd.ref = make_uint4(__float_as_uint(g.x), __float_as_uint(g.y), __float_as_uint(g.z), __float_as_uint(g.w));
     } else {
+#if MPT_OT_QNODES
+        const float4* qq = ac.qnodes + 4u * (size_t)n;
+        const float4 w0 = qq[0], w1 = qq[1], w2 = qq[2], w3 = qq[3];
+        {   // (no branch on the loaded data: a test of w0 before the other three loads are issued costs a second round trip per visit —
+            //  measured: 72.6 ms instead of 64.7.  A node that cannot be quantised gets boxes that every ray enters, see k_quantize_nodes)
+            const uint32_t qlx = __float_as_uint(w1.z), qly = __float_as_uint(w1.w), qlz = __float_as_uint(w2.x), qhx = __float_as_uint(w2.y),
+                           qhy = __float_as_uint(w2.z), qhz = __float_as_uint(w2.w);
+            nd.ref = make_uint4(__float_as_uint(w3.x), __float_as_uint(w3.y), __float_as_uint(w3.z), __float_as_uint(w3.w));
+#define OT_DEQ(word, k, s_, o_) fmaf((float)(((word) >> (8 * (k))) & 255u), (s_), (o_))
+            nd.lx = make_float4(OT_DEQ(qlx, 0, w0.w, w0.x), OT_DEQ(qlx, 1, w0.w, w0.x), OT_DEQ(qlx, 2, w0.w, w0.x), OT_DEQ(qlx, 3, w0.w, w0.x));
+            nd.hx = make_float4(OT_DEQ(qhx, 0, w0.w, w0.x), OT_DEQ(qhx, 1, w0.w, w0.x), OT_DEQ(qhx, 2, w0.w, w0.x), OT_DEQ(qhx, 3, w0.w, w0.x));
+            nd.ly = make_float4(OT_DEQ(qly, 0, w1.x, w0.y), OT_DEQ(qly, 1, w1.x, w0.y), OT_DEQ(qly, 2, w1.x, w0.y), OT_DEQ(qly, 3, w1.x, w0.y));
+            nd.hy = make_float4(OT_DEQ(qhy, 0, w1.x, w0.y), OT_DEQ(qhy, 1, w1.x, w0.y), OT_DEQ(qhy, 2, w1.x, w0.y), OT_DEQ(qhy, 3, w1.x, w0.y));
+            nd.lz = make_float4(OT_DEQ(qlz, 0, w1.y, w0.z), OT_DEQ(qlz, 1, w1.y, w0.z), OT_DEQ(qlz, 2, w1.y, w0.z), OT_DEQ(qlz, 3, w1.y, w0.z));
+            nd.hz = make_float4(OT_DEQ(qhz, 0, w1.y, w0.z), OT_DEQ(qhz, 1, w1.y, w0.z), OT_DEQ(qhz, 2, w1.y, w0.z), OT_DEQ(qhz, 3, w1.y, w0.z));
+#undef OT_DEQ
+            // an empty child slot: both x planes at +inf, as in the float form (no walked ray enters it)
+            const float inf = __uint_as_float(0x7F800000u);
+            if (nd.ref.x == 0xFFFFFFFFu) nd.lx.x = nd.hx.x = inf;
+            if (nd.ref.y == 0xFFFFFFFFu) nd.lx.y = nd.hx.y = inf;
+            if (nd.ref.z == 0xFFFFFFFFu) nd.lx.z = nd.hx.z = inf;
+            if (nd.ref.w == 0xFFFFFFFFu) nd.lx.w = nd.hx.w = inf;
+            return nd;
+        }
+#else
         const float4* q = ac.nodes + MPT_OT_NODE_STRIDE * (size_t)n;
         nd.lx = q[0];
         nd.ly = q[1];
@@ -190,7 +237,28 @@ __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds,
         nd.hz = q[5];
         const float4 g = q[6];
         nd.ref = make_uint4(__float_as_uint(g.x), __float_as_uint(g.y), __float_as_uint(g.z), __float_as_uint(g.w));
+#endif
+#if defined(MPT_OT_DIAG_DUP) && !MPT_OT_QNODES   // sensitivity experiment: 3 (or 7) more 16-byte loads of the same node (vector-L1 hits: tag look-ups only), one wait
+        {
+            v4f x0, x1, x2;
+            asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx4 %2, %3, off offset:32\n\t"
+#if MPT_OT_DIAG_DUP > 3
+                         "global_load_dwordx4 %0, %3, off offset:48\n\tglobal_load_dwordx4 %1, %3, off offset:64\n\tglobal_load_dwordx4 %2, %3, off offset:80\n\t"
+                         "global_load_dwordx4 %0, %3, off offset:96\n\t"
+#endif
+                         "s_waitcnt vmcnt(0)" : "=&v"(x0), "=&v"(x1), "=&v"(x2) : "v"(q) : "memory");
+            asm volatile("" ::"v"(x0), "v"(x1), "v"(x2));
+        }
+#endif
     }
+#ifdef MPT_OT_DIAG_VALU  // sensitivity experiment: MPT_OT_DIAG_VALU more vector instructions per node visit
+    {
+        float x = nd.lx.x;
+#pragma unroll
+        for (int k = 0; k < MPT_OT_DIAG_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));
+        asm volatile("" ::"v"(x));
+    }
+#endif
     return nd;
 }
 // entry distance of the ray into one child box as a sort key: float bits with the child slot in the two low bits
@@ -350,10 +418,18 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
 #ifdef MPT_OT_TIMES
         wc.ot_rounds++;
 #endif
-        const uint32_t n_entered = (uint32_t)__popcll(__ballot(cur < MPT_OT_LEAF && (!BUDGETED || trips < budget)));
-        while (cur < MPT_OT_LEAF && (!BUDGETED || trips < budget)) {
+        // The node loop is wave-uniform in its CONTROL (round 4): the wave goes round while enough of its lanes search, a lane that
+        // has found its leaf sits the trip out under the exec mask.  So `trips` — the wave's count, which a lane that left early has
+        // to adopt — is one scalar register; with per-lane loop exits (round 3) it had to be maximised over the lanes after every
+        // round: six dependent ds_bpermute + waits, ~600 cycles, three node trips apart.
+        const uint32_t n_entered = (uint32_t)__popcll(__ballot(cur < MPT_OT_LEAF)) * MPT_OT_EARLY_NUM;
+        for (;;) {
+            if (BUDGETED && trips >= budget) break;
             // few lanes still searching, the others hold a leaf: test the leaves now, the search resumes afterwards
-            if ((uint32_t)__popcll(__ballot(true)) * MPT_OT_EARLY < n_entered * MPT_OT_EARLY_NUM) break;
+            const uint32_t n_search = (uint32_t)__popcll(__ballot(cur < MPT_OT_LEAF));
+            if (n_search == 0u || n_search * MPT_OT_EARLY < n_entered) break;
+            if (BUDGETED) ++trips;
+            if (!(cur < MPT_OT_LEAF)) continue;
             // (taking ONE source per trip for the whole wave — LDS only when every searching lane is at a staged node —
             // instead of a per-lane choice was measured on bunny x20: no difference, 20.7 ms either way)
             const OtNode nd = ot_load_node<ALL_LDS>(ac, lds, cur);
@@ -367,7 +443,6 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                 wc.aabb_hits += (k0 < MPT_OT_KEY_MISS) + (k1 < MPT_OT_KEY_MISS) + (k2 < MPT_OT_KEY_MISS) + (k3 < MPT_OT_KEY_MISS);
                 if (first_active_lane()) wc.node_iters++;
             }
-            if (BUDGETED) trips++;
 #ifdef MPT_OT_TIMES
             if (first_active_lane()) wc.ot_node_trips++;
             wc.ot_node_lanes++;
@@ -384,7 +459,6 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                 cur = ot_pop_next(st, sp, lim);
             }
         }
-        if (BUDGETED) trips = wave_max_u32(trips);  // a lane that left the loop early adopts the trips the others made
         OT_WTOC(ot_node_cycles);
         if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF) {  // a leaf: primitives [first, first + count) in index order
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
@@ -503,6 +577,75 @@ __device__ __forceinline__ void closest_hit_ordered(const AccelDev& ac, const Sc
     }
 }
 
+// 112-byte float nodes -> 64-byte nodes (see AccelDev).  One thread per node; runs once per scene (mpt_upload_scene, mpt_build_and_upload).
+__global__ void k_quantize_nodes(const float4* nodes, uint32_t n_nodes, float4* qnodes, uint32_t* n_float /* nodes whose boxes could not be quantised */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float4* q = nodes + MPT_OT_NODE_STRIDE * (size_t)i;
+    float lo[3][4], hi[3][4];
+    uint32_t ref[4];
+    {
+        const float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
+        const float L[3][4] = {{a.x, a.y, a.z, a.w}, {b.x, b.y, b.z, b.w}, {c.x, c.y, c.z, c.w}};
+        const float H[3][4] = {{d.x, d.y, d.z, d.w}, {e.x, e.y, e.z, e.w}, {f.x, f.y, f.z, f.w}};
+        for (int ax = 0; ax < 3; ++ax)
+            for (int j = 0; j < 4; ++j) lo[ax][j] = L[ax][j], hi[ax][j] = H[ax][j];
+        ref[0] = __float_as_uint(g.x), ref[1] = __float_as_uint(g.y), ref[2] = __float_as_uint(g.z), ref[3] = __float_as_uint(g.w);
+    }
+    bool ok = true;
+    float o[3] = {0.0f, 0.0f, 0.0f}, s[3] = {1.0f, 1.0f, 1.0f};
+    uint32_t ql[3] = {0u, 0u, 0u}, qh[3] = {0u, 0u, 0u};
+    for (int ax = 0; ax < 3; ++ax) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int j = 0; j < 4; ++j) {
+            if (ref[j] == 0xFFFFFFFFu) continue;
+            if (!(isfinite(lo[ax][j]) && isfinite(hi[ax][j]) && lo[ax][j] <= hi[ax][j])) ok = false;
+            mn = fminf(mn, lo[ax][j]);
+            mx = fmaxf(mx, hi[ax][j]);
+        }
+        if (!(mn <= mx)) {   // no child at all (cannot happen) or nothing finite
+            ok = false;
+            mn = mx = 0.0f;
+        }
+        float sc = (mx - mn) / 255.0f;
+        if (!(sc > 1e-30f)) sc = 1e-30f;
+        for (int k = 0; k < 64 && fmaf(255.0f, sc, mn) < mx; ++k) sc = nextafterf(sc, INFINITY);
+        if (!isfinite(sc) || !isfinite(fmaf(255.0f, sc, mn)) || fmaf(255.0f, sc, mn) < mx) ok = false;
+        o[ax] = mn;
+        s[ax] = sc;
+        for (int j = 0; j < 4; ++j) {
+            uint32_t a = 255u, b = 0u;   // an empty slot: decoded planes are overwritten with +inf by the walk
+            if (ref[j] != 0xFFFFFFFFu && ok) {
+                float fa = floorf((lo[ax][j] - mn) / sc), fb = ceilf((hi[ax][j] - mn) / sc);
+                fa = fminf(fmaxf(fa, 0.0f), 255.0f);
+                fb = fminf(fmaxf(fb, 0.0f), 255.0f);
+                a = (uint32_t)fa;
+                b = (uint32_t)fb;
+                while (a > 0u && fmaf((float)a, sc, mn) > lo[ax][j]) --a;      // the decoded plane, in the walk's own arithmetic,
+                while (b < 255u && fmaf((float)b, sc, mn) < hi[ax][j]) ++b;    // must not cut into the float box
+                if (fmaf((float)a, sc, mn) > lo[ax][j] || fmaf((float)b, sc, mn) < hi[ax][j]) ok = false;
+            }
+            ql[ax] |= a << (8 * j);
+            qh[ax] |= b << (8 * j);
+        }
+    }
+    float4* out = qnodes + 4u * (size_t)i;
+    if (!ok) {   // a plane that is not finite, or an extent that overflows (degenerate input): boxes from -2.5e38 to +2.5e38 on every axis —
+                 // every ray enters every child, whose own node or primitives are then tested as always (conservative; counted)
+        atomicAdd(n_float, 1u);
+        for (int ax = 0; ax < 3; ++ax) {
+            o[ax] = -2.5e38f;
+            s[ax] = 1.9607843e36f;   // (5e38 / 255)
+            ql[ax] = 0u;
+            qh[ax] = 0xFFFFFFFFu;
+        }
+    }
+    out[0] = make_float4(o[0], o[1], o[2], s[0]);
+    out[1] = make_float4(s[1], s[2], __uint_as_float(ql[0]), __uint_as_float(ql[1]));
+    out[2] = make_float4(__uint_as_float(ql[2]), __uint_as_float(qh[0]), __uint_as_float(qh[1]), __uint_as_float(qh[2]));
+    out[3] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+}
+
 __device__ __forceinline__ void ot_stage(const SceneDev& sc, const AccelDev& ac, float4* lds) {
     const uint32_t n4 = ac.n_lds_nodes * 7u, p4 = sc.n_lds_prims * 3u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {  // 7 of a node's MPT_OT_NODE_STRIDE float4 (the rest is padding)
@@ -524,7 +667,7 @@ __device__ __forceinline__ OtStack ot_stack(const AccelDev& ac, float4* lds_raw,
 }
 
 // A ring record is read once: -DMPT_OT_NT_POP makes the pops non-temporal loads, so that they do not displace nodes and
-// primitives from the vector L1 (the walk is bound by its tag look-ups and misses).
+// primitives from the vector L1.  MEASURED AND REJECTED (round 4): bunny x20 67.9 ms against 64.3.
 __device__ __forceinline__ float4 ot_pop4(const float4* p) {
 #ifdef MPT_OT_NT_POP
     const v4f_nt v = __builtin_nontemporal_load((const v4f_nt*)p);
@@ -715,6 +858,21 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         }
         // the rest of a record is not needed by the tree walk: ring M steps load it afterwards
         auto load_rest = [&]() {
+#if MPT_WL_DIET   // the 48 + 16-byte record of mpt_kernels.h (WaveRings): tl only for the rays that have gathered light
+            const uint4 ia = ot_pop4u(ring.ia + at);
+            ps.thr.z = __uint_as_float(ia.x);
+            ps.path = ia.y;
+            g.pixel = ia.z;
+            ps.bounce = ia.w & 0xFFu;
+            g.sample = sample_of_path(pp, ps.path);
+            ps.L = f3(0.0f, 0.0f, 0.0f);
+            ps.La = 0.0f;
+            if ((ia.w & MPT_RING_HAS_LIGHT) != 0u) {
+                const float4 cc = ot_pop4(ring.tl + at);
+                ps.L = f3(cc.x, cc.y, cc.z);
+                ps.La = cc.w;
+            }
+#else
             const float4 cc = ot_pop4(ring.tl + at);
             const uint4 ia = ot_pop4u(ring.ia + at);
             ps.thr.z = cc.x;
@@ -724,6 +882,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             ps.bounce = ia.w >> 27;
             g.pixel = ia.z;
             g.sample = ia.w & 0x07FFFFFFu;
+#endif
             g.lit_seed = 0;
             if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
         };
@@ -837,8 +996,16 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             if (dest != MPT_OT_NONE) {
                 ring.od[to] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
                 ring.dt[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+#if MPT_WL_DIET
+                {
+                    const bool lit = ring_has_light(ps);
+                    ring.ia[to] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
+                    if (lit) ring.tl[to] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
+                }
+#else
                 ring.tl[to] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
                 ring.ia[to] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+#endif
                 if (dest >= MPT_OT_RING_M) {
                     // a ray parked by a top test starts its walk at the root (walk_cur = 0, walk_sp = 0 there)
                     ring.tv[to] = make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,

@@ -123,6 +123,7 @@ struct SahState {
     uint32_t n_nodes;  // inner nodes created
     int root;          // -1: no items
     uint32_t n_items;
+    uint32_t cur[4];   // the level being processed: tasks, big tasks, small tasks (k_sah_flip: cur = next, next = 0), level
 };
 __device__ __forceinline__ float half_area4(float4 lo, float4 hi) {
     const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
@@ -162,6 +163,27 @@ __global__ void k_sah_init(const uint32_t* count /* device word, or null */, uin
         st->n_next = 1u;
     }
 }
+// Start of a level, one thread: the counts the previous level pushed become the level's own (the kernels of the level read them
+// from the device: their grids are sized from an upper bound, the host does not wait for the counts), the push counters start
+// from zero, and the counts go to a slot of pinned host memory with a stamp behind them — the host reads them one or two
+// levels LATER, to size the grids of the levels it enqueues while the device is busy with this one (run_sah).
+__global__ void k_sah_flip(SahState* st, uint32_t level, uint32_t stamp, volatile uint32_t* host_slot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t a = st->n_next, b = st->n_next_big, c = st->n_next_small;
+    st->cur[0] = a;
+    st->cur[1] = b;
+    st->cur[2] = c;
+    st->cur[3] = level;
+    st->n_next = 0u;
+    st->n_next_big = 0u;
+    st->n_next_small = 0u;
+    host_slot[0] = a;
+    host_slot[1] = b;
+    host_slot[2] = c;
+    __threadfence_system();
+    host_slot[3] = stamp;
+    __threadfence_system();
+}
 #define MPT_SAH_WAVES 16   // tasks (waves) per workgroup
 __device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int parent, uint32_t side, int id) {
     if (parent < 0) st->root = id;
@@ -185,8 +207,9 @@ __device__ __forceinline__ void sah_push_children(SahState* st, int2* s_child, S
     else next[atomicAdd(&st->n_next, 1u)] = R;
 }
 __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi,
-                                                                  const SahTask* tasks, uint32_t n_tasks, SahTask* next, SahTask* next_big, SahTask* next_small,
+                                                                  const SahTask* tasks, SahTask* next, SahTask* next_big, SahTask* next_small,
                                                                   SahState* st, int2* s_child, float4* s_lo, float4* s_hi) {
+    const uint32_t n_tasks = st->cur[0];   // (the grid is sized from an upper bound: waves beyond the count hold an empty task)
     __shared__ int bins[MPT_SAH_WAVES][3][16][7];   // per wave: (lo xyz, hi xyz as ordered ints, primitive count) per axis and bin
     __shared__ uint32_t s_push[MPT_SAH_WAVES][6];   // per wave: b, e, nlft, node, first item left / right (e = 0: nothing to push)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -364,7 +387,8 @@ struct SahBig {
     unsigned long long largest;   // sah_area_key of the item with the largest box
 };
 __device__ __forceinline__ uint32_t sah_chunks(const SahTask& t) { return (t.e - t.b + MPT_SAH_CHUNK - 1u) / MPT_SAH_CHUNK; }
-__global__ __launch_bounds__(1024) void k_big_prep(const SahTask* tasks, uint32_t n_big, SahBig* big, uint32_t* coff /* [n_big + 1] */) {
+__global__ __launch_bounds__(1024) void k_big_prep(const SahTask* tasks, const SahState* st, SahBig* big, uint32_t* coff /* [n_big + 1] */) {
+    const uint32_t n_big = st->cur[1];
     __shared__ uint32_t s_w[16], s_run;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) s_run = 0u;
@@ -404,8 +428,9 @@ __device__ __forceinline__ uint32_t sah_task_of_chunk(const uint32_t* coff, uint
     }
     return lo;
 }
-__global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const float4* in_lo, const float4* in_hi, const SahTask* tasks, uint32_t n_big,
+__global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const float4* in_lo, const float4* in_hi, const SahTask* tasks, const SahState* st,
                                                                       const uint32_t* coff, SahBig* big) {
+    const uint32_t n_big = st->cur[1];
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
     if (c >= coff[n_big]) return;
     const uint32_t t = sah_task_of_chunk(coff, n_big, c);
@@ -465,6 +490,7 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
     __shared__ float s_cost[48];
     const uint32_t tid = threadIdx.x;
     const int TOP = 2 * n - 1;
+    if (blockIdx.x >= st->cur[1]) return;   // (grid sized from an upper bound)
     const SahTask task = tasks[blockIdx.x];
     SahBig& G = big[blockIdx.x];
     const uint32_t b = task.b, e = task.e, m = e - b;
@@ -565,8 +591,9 @@ __device__ __forceinline__ bool sah_big_left(const SahSplit& s, uint32_t i, floa
     q = q < 0 ? 0 : (q > 15 ? 15 : q);
     return q <= s.split;
 }
-__global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float4* in_lo, const float4* in_hi, const SahTask* tasks, uint32_t n_big,
+__global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float4* in_lo, const float4* in_hi, const SahTask* tasks, const SahState* st,
                                                                      const uint32_t* coff, const SahBig* big, uint32_t* chunk_left) {
+    const uint32_t n_big = st->cur[1];
     __shared__ uint32_t s_w[MPT_SAH_CHUNK_THREADS / 64u];
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (c >= coff[n_big]) return;
@@ -586,7 +613,8 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float
     }
 }
 __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
-                                                                       uint32_t n_big, const uint32_t* coff, SahBig* big, const uint32_t* chunk_left) {
+                                                                       const SahState* st, const uint32_t* coff, SahBig* big, const uint32_t* chunk_left) {
+    const uint32_t n_big = st->cur[1];
     constexpr uint32_t NW = MPT_SAH_CHUNK_THREADS / 64u;
     __shared__ uint32_t s_wl[NW], s_wr[NW], s_before[NW];
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -641,10 +669,10 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const flo
         __syncthreads();
     }
 }
-__global__ void k_big_push(const SahTask* tasks, uint32_t n_big, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
+__global__ void k_big_push(const SahTask* tasks, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
                            SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_big) return;
+    if (t >= st->cur[1]) return;
     uint32_t nlft = 0;
     for (uint32_t c = coff[t]; c < coff[t + 1u]; ++c) nlft += chunk_left[c];
     sah_push_children(st, s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1]);
@@ -656,8 +684,9 @@ __global__ void k_big_push(const SahTask* tasks, uint32_t n_big, const uint32_t*
 // shuffles, the partition by ds_permute), so no task of the bottom levels is ever queued.  Same algorithm and same choices as
 // k_sah_level (16 bins over the box centres, cost = area * primitives, ties to the lowest (axis, split)); a lane prices the
 // three planes behind its own item's bins, which are all the planes that separate anything.
-__global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, uint32_t n_tasks, SahState* st,
+__global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahState* st,
                                                    int2* s_child, float4* s_lo, float4* s_hi) {
+    const uint32_t n_tasks = st->cur[2];   // (the grid is sized from an upper bound)
     constexpr uint32_t G = MPT_SAH_SMALL;
     static_assert(G == 8u || G == 16u, "MPT_SAH_SMALL: 8 or 16");
     const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / G, lane = threadIdx.x & 63u, gl = lane & (G - 1u), gbase = lane & ~(G - 1u);
@@ -809,8 +838,14 @@ struct SahTree {
     SahState* st = nullptr;   // on the device: root, n_nodes
 };
 // it_lo / it_hi: the items (device, consumed: the partitions ping-pong between them and two scratch arrays).  The item count
-// is *d_count if d_count is not null (a device word), else count_host; max_items bounds it.  pin: >= 64 bytes of pinned
-// host memory for the per-level read-back.  The stream is synchronised once per level (about 12 + log2(items / 8) levels).
+// is *d_count if d_count is not null (a device word), else count_host; max_items bounds it.  pin: >= 1 KiB of pinned host memory.
+//
+// No host wait inside the level loop (round 4; round 3 synchronised the stream once per level to read three counters: ~22 idle
+// gaps of 30-40 us for 1 M items).  The kernels of a level read their task counts from the device (SahState::cur, k_sah_flip) and
+// are launched on grids sized from an UPPER BOUND — a level at most doubles the number of tasks, so the bound comes from the
+// exact counts of one or two levels before, which k_sah_flip left in pinned memory with a stamp.  The host only ever waits for a
+// level the device has already passed (or is about to): the device always has the next level queued.  The loop ends one or two
+// (empty) levels late; waves and workgroups beyond the true counts return at once.
 static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int top, const uint32_t* d_count, uint32_t count_host, uint32_t max_items,
                           float4* it_lo_a, float4* it_hi_a, SahTree& T) {
     float4 *it_lo_b, *it_hi_b;
@@ -835,45 +870,83 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
     MPT_LB(sc.alloc(&T.hi, max_items));
     // (k_sah_* take n with top = 2n - 1)
     const int n = (top + 1) / 2;
+    // eight slots of (tasks, big, small, stamp) in pinned memory, behind the words other read-backs of the build use
+    static uint32_t s_epoch = 0;
+    const uint32_t epoch = (++s_epoch & 0xFFFFu) << 16;
+    volatile uint32_t* slots = pin + 64;
+    uint32_t* d_pin = nullptr;
+    MPT_LB(hipHostGetDevicePointer((void**)&d_pin, pin, 0));
+    for (int q = 0; q < 8; ++q) slots[4 * q + 3] = 0u;
     hipLaunchKernelGGL(k_sah_init, dim3(1), dim3(64), 0, stream, d_count, count_host, T.st, tasks_a, big_a, small_a);
-    SahState& h = *(SahState*)pin;
-    MPT_LB(hipMemcpyAsync(&h, T.st, sizeof h, hipMemcpyDeviceToHost, stream));
-    MPT_LB(hipStreamSynchronize(stream));
-    uint32_t n_tasks = h.n_next, n_big = h.n_next_big, n_small = h.n_next_small;
-    for (int level = 0; level < 4096 && (n_tasks | n_big | n_small) != 0u; ++level) {
-        MPT_LB(hipMemsetAsync(&T.st->n_next, 0, 12, stream));   // n_next, n_next_big, n_next_small
-        if (n_big) {
-            const uint32_t chunks = max_items / MPT_SAH_CHUNK + n_big;   // >= sum of ceil(items / chunk) over the level's big tasks
-            hipLaunchKernelGGL(k_big_prep, dim3(1), dim3(1024), 0, stream, (const SahTask*)big_a, n_big, bigs, coff);
+    const uint32_t cap_mid = max_items / (MPT_SAH_SMALL + 1u) + 2u, cap_small = max_items / 2u + 2u;
+    auto wait_slot = [&](int level, uint32_t out[3]) -> hipError_t {   // the counts of `level`, once k_sah_flip(level) has run
+        volatile uint32_t* sl = slots + 4 * (level & 7);
+        const uint32_t want = epoch | (uint32_t)(level + 1);
+        for (unsigned long long spin = 0;; ++spin) {
+            if (sl[3] == want) break;
+            if ((spin & 0xFFFu) == 0xFFFu) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return q;
+                if (q == hipSuccess && sl[3] != want) return hipErrorUnknown;   // the stream is drained and the stamp never came
+            }
+        }
+        out[0] = sl[0];
+        out[1] = sl[1];
+        out[2] = sl[2];
+        return hipSuccess;
+    };
+    uint32_t b_mid = 1u, b_big = 1u, b_small = 1u;   // upper bounds of the level about to be enqueued (level 0: the root task, of one kind)
+    int known = -1;                                   // the latest level whose exact counts the host has read
+    bool done = false;
+    int level = 0;
+    for (; level < 4096 && !done; ++level) {
+        hipLaunchKernelGGL(k_sah_flip, dim3(1), dim3(64), 0, stream, T.st, (uint32_t)level, epoch | (uint32_t)(level + 1), (volatile uint32_t*)(d_pin + 64 + 4 * (level & 7)));
+        if (b_big) {
+            const uint32_t chunks = max_items / MPT_SAH_CHUNK + b_big;   // >= sum of ceil(items / chunk) over the level's big tasks
+            hipLaunchKernelGGL(k_big_prep, dim3(1), dim3(1024), 0, stream, (const SahTask*)big_a, (const SahState*)T.st, bigs, coff);
             hipLaunchKernelGGL(k_big_bounds, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
-                               n_big, (const uint32_t*)coff, bigs);
-            hipLaunchKernelGGL(k_big_pick, dim3(n_big), dim3(MPT_SAH_BIG_THREADS), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a, bigs,
+                               (const SahState*)T.st, (const uint32_t*)coff, bigs);
+            hipLaunchKernelGGL(k_big_pick, dim3(b_big), dim3(MPT_SAH_BIG_THREADS), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a, bigs,
                                T.st, T.child, T.lo, T.hi);
             hipLaunchKernelGGL(k_big_count, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
-                               n_big, (const uint32_t*)coff, (const SahBig*)bigs, chunk_left);
+                               (const SahState*)T.st, (const uint32_t*)coff, (const SahBig*)bigs, chunk_left);
             hipLaunchKernelGGL(k_big_scatter, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b, it_hi_b,
-                               (const SahTask*)big_a, n_big, (const uint32_t*)coff, bigs, (const uint32_t*)chunk_left);
-            hipLaunchKernelGGL(k_big_push, dim3((n_big + 255u) / 256u), dim3(256), 0, stream, (const SahTask*)big_a, n_big, (const uint32_t*)coff, (const SahBig*)bigs,
+                               (const SahTask*)big_a, (const SahState*)T.st, (const uint32_t*)coff, bigs, (const uint32_t*)chunk_left);
+            hipLaunchKernelGGL(k_big_push, dim3((b_big + 255u) / 256u), dim3(256), 0, stream, (const SahTask*)big_a, (const uint32_t*)coff, (const SahBig*)bigs,
                                (const uint32_t*)chunk_left, tasks_b, big_b, small_b, T.st, T.child);
         }
-        if (n_tasks)
-            hipLaunchKernelGGL(k_sah_level, dim3((n_tasks + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES), dim3(64 * MPT_SAH_WAVES), 0, stream, n, (const float4*)it_lo_a,
-                               (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, n_tasks, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi);
-        if (n_small)
-            hipLaunchKernelGGL(k_sah_small, dim3((uint32_t)(((size_t)n_small * MPT_SAH_SMALL + 255) / 256)), dim3(256), 0, stream, n, (const float4*)it_lo_a,
-                               (const float4*)it_hi_a, (const SahTask*)small_a, n_small, T.st, T.child, T.lo, T.hi);
-        MPT_LB(hipMemcpyAsync(&h, T.st, sizeof h, hipMemcpyDeviceToHost, stream));
-        MPT_LB(hipStreamSynchronize(stream));
-        n_tasks = h.n_next;
-        n_big = h.n_next_big;
-        n_small = h.n_next_small;
+        if (b_mid)
+            hipLaunchKernelGGL(k_sah_level, dim3((b_mid + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES), dim3(64 * MPT_SAH_WAVES), 0, stream, n, (const float4*)it_lo_a,
+                               (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi);
+        if (b_small)
+            hipLaunchKernelGGL(k_sah_small, dim3((uint32_t)(((size_t)b_small * MPT_SAH_SMALL + 255) / 256)), dim3(256), 0, stream, n, (const float4*)it_lo_a,
+                               (const float4*)it_hi_a, (const SahTask*)small_a, T.st, T.child, T.lo, T.hi);
+        MPT_LB(hipGetLastError());
+        // bounds of level + 1 from the newest exact counts: those of level - 1 at the latest (the device is past them or about to
+        // be: the wait is short and the device keeps `level` in its queue meanwhile), those of `level` if they are there already
+        uint32_t c[3];
+        int from = level - 1;
+        if (slots[4 * (level & 7) + 3] == (epoch | (uint32_t)(level + 1))) from = level;
+        if (from >= 0) {
+            MPT_LB(wait_slot(from, c));
+            known = from;
+            if ((c[0] | c[1] | c[2]) == 0u) done = true;   // nothing was left at `from`: the levels behind it are empty too
+            const uint32_t steps = (uint32_t)(level + 1 - from);   // 1 or 2 doublings
+            const unsigned long long g = 1ull << steps, parents = (unsigned long long)c[0] + c[1];
+            b_big = (uint32_t)std::min<unsigned long long>(g * c[1], max_big);
+            b_mid = (uint32_t)std::min<unsigned long long>(g * parents, cap_mid);
+            b_small = (uint32_t)std::min<unsigned long long>(g * parents, cap_small);
+        } else {   // level 0 enqueued, nothing read yet: its (at most one) task has at most two children
+            b_big = b_mid = b_small = 2u;
+        }
         std::swap(tasks_a, tasks_b);
         std::swap(big_a, big_b);
         std::swap(small_a, small_b);
         std::swap(it_lo_a, it_lo_b);
         std::swap(it_hi_a, it_hi_b);
     }
-    if ((n_tasks | n_big | n_small) != 0u) return hipErrorUnknown;
+    (void)known;
+    if (!done) return hipErrorUnknown;
     return hipGetLastError();
 }
 }  // namespace mpt_sah

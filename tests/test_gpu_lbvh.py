@@ -514,3 +514,66 @@ def test_config4_at_its_real_size_on_the_device_built_tree(gpu_ctx, tmp_path):
     ref, _ = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG_PHILOX, bsdf_mode=ob.BSDF_SCATTER, max_depth=16,
                        accumulate=1, sample_count=4, seed=(1, 0), rows=rows, threads=8)
     np.testing.assert_array_equal(whole[rows[0]:rows[1]].view(np.uint32), ref[rows[0]:rows[1]].view(np.uint32))
+
+
+def test_a_ground_quad_hangs_under_the_root_like_a_ground_sphere(gpu_ctx):
+    """Round 4: the device builder keeps every item whose box dwarfs the rest out of its SAH (>= 2^10 x the median extent by
+    binades), not only spheres: a ground QUAD of two 2 x 10^4-unit triangles under the bunny stretches the root box — and the
+    bounds of the box centres the SAH bins over — exactly as scene.xml's ground sphere does.  The two triangles must hang under
+    the root in a leaf of their own, the root's other child must be the SAH tree of the mesh with the mesh's own box, and that
+    tree must cost what the tree of the mesh ALONE costs (the quad changes nothing below the root); both walks agree with the
+    oracle on the downloaded tree."""
+    from metalpathtracer_amd import capi, host
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(scene_path("scene.xml"), sc)
+    assert st == 0, log
+    sc.sortPrimitives()
+    prims0, mats0 = sc.packed_primitives()
+    tri = np.asarray(prims0).reshape(-1, 12)
+    tri = tri[tri[:, 3] == 1.0]                                       # the bunny alone (the three spheres dropped)
+    mats = np.zeros((len(tri) + 2, 8), np.float32)
+    mats[:, 0:3] = 0.7
+    S = 1.0e4
+    quad = np.zeros((2, 12), np.float32)
+    quad[:, 3] = 1.0
+    quad[0, 0:3], quad[0, 4:7], quad[0, 8:11] = (-S, -0.5, -S), (S, -0.5, -S), (S, -0.5, S)
+    quad[1, 0:3], quad[1, 4:7], quad[1, 8:11] = (-S, -0.5, -S), (S, -0.5, S), (-S, -0.5, S)
+    alone = tri.copy()
+    gpu_ctx.build_and_upload(alone, mats[:len(alone)])
+    bvh_a, idx_a = gpu_ctx.download_bvh()
+    cost_alone = _sah_cost(bvh_a, idx_a, alone)
+    both = np.concatenate([tri[:100], quad, tri[100:]])               # (the quad somewhere in the middle of the array)
+    gpu_ctx.build_and_upload(both, mats)
+    bvh, idx = gpu_ctx.download_bvh()
+    raw = bvh.reshape(-1, 8)
+    _check_tree(raw, idx, both)
+    lf, cnt = raw[:, 3].copy().view(np.int32), raw[:, 7].copy().view(np.int32)
+    assert cnt[0] <= 0                                                # the root is an inner node ...
+    kids = [int(lf[0]), int(-cnt[0])]
+    leaf = [k for k in kids if cnt[k] > 0]
+    assert len(leaf) == 1 and cnt[leaf[0]] == 2                       # ... one child is a leaf of two primitives:
+    assert sorted(idx[lf[leaf[0]]:lf[leaf[0]] + 2].tolist()) == [100, 101]   # the quad
+    other = [k for k in kids if k != leaf[0]][0]
+    v = np.stack([tri[:, 0:3], tri[:, 4:7], tri[:, 8:11]], 1)
+    lo, hi = v.min((0, 1)), v.max((0, 1))
+    pad = 1e-3 * (hi - lo).max()
+    assert (raw[other, 0:3] >= lo - pad).all() and (raw[other, 4:7] <= hi + pad).all()   # the mesh's own box: not stretched by the quad
+    # cost of the mesh part (nodes without a quad triangle below them), by the measure of _sah_cost with the quad masked out like a sphere
+    masked = both.copy()
+    masked[100:102, 3] = 0.0
+    cost_with = _sah_cost(raw, idx, masked)
+    assert abs(cost_with - cost_alone) <= 0.03 * cost_alone, (cost_with, cost_alone)
+    rng = np.random.default_rng(5)
+    m = 4096
+    o = (rng.normal(size=(m, 3)) * 30 + (0, 20, 0)).astype(np.float32)
+    d = (rng.normal(size=(m, 3)) * 8 + (0, 5, 0) - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0, p0, _, _ = gpu_ctx.trace_rays(o, d)
+    t1, p1, _, _, _ = gpu_ctx.trace_rays_ordered(o, d)
+    np.testing.assert_array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    np.testing.assert_array_equal(p0, p1)
+    buffers = (bvh, both.reshape(-1, 3, 4), mats.reshape(-1, 2, 4), idx)
+    for i in range(0, m, 97):
+        to, po, _, _ = ob.first_hit(o[i], d[i], buffers)
+        assert po == p0[i] and (po < 0 or np.float32(to) == t0[i]), i
+    assert (p0 >= 0).sum() > m // 4
