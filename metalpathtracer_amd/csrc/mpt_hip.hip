@@ -174,8 +174,8 @@ static const void* wavelocal_kernel(bool count, bool all_lds) {
     return all_lds ? (const void*)k_wavelocal<false, true> : (const void*)k_wavelocal<false, false>;
 }
 
-#define MPT_LDS_MATS 32u                        // materials staged in LDS (32 B each)
-#define MPT_LDS_EXTRA (256 + MPT_LDS_MATS * 32)  // descriptor copy + material table behind the scene image
+#define MPT_LDS_MATS MPT_LDS_MATS_N               // materials staged in LDS (32 B each; mpt_kernels.h)
+#define MPT_LDS_EXTRA (MPT_LDS_CFG_F4 * 16 + MPT_LDS_MATS * 32)  // material table + descriptor copy (k_step) / configuration block (k_wavelocal, k_ordered) behind the scene image
 
 #define HIPCHK(call)                                                                        \
     do {                                                                                    \
@@ -313,8 +313,7 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
 }
 
 static void free_ot_rings(OtRings& r) {
-    hipFree(r.od); hipFree(r.dt); hipFree(r.tl); hipFree(r.ia); hipFree(r.tv);
-    for (auto& p : r.sk) hipFree(p);
+    hipFree(r.base);
     r = OtRings{};
 }
 static void free_queues(Lane& L) {
@@ -351,11 +350,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
         hipFree(L.d_slots);
         hipFree(L.d_desc);
         hipFree(L.d_ctr);
-        hipFree(L.ring.od);
-        hipFree(L.ring.dt);
-        hipFree(L.ring.tl);
-        hipFree(L.ring.ia);
-        hipFree(L.ring.tv);
+        hipFree(L.ring.base);
         free_ot_rings(L.ot_ring);
         free_queues(L);
         if (L.h_done) hipHostFree(L.h_done);
@@ -913,7 +908,7 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     a.lds_always_off = 7u * a.n_lds_nodes;
     s.lds_prim_off = a.lds_always_off + 5u * a.n_always;
     s.lds_mat_off = s.lds_prim_off + 3u * s.n_lds_prims;
-    const uint32_t image4 = s.lds_mat_off + 2u * s.n_lds_mats;
+    const uint32_t image4 = s.lds_mat_off + 2u * MPT_LDS_MATS + MPT_LDS_CFG_F4;   // (+ the kernel's configuration block behind the material table)
     a.lds_stack_off = image4 * 16u;
     a.stack_depth = stack_depth;
     a.eps_abs = ctx->acc_eps_abs;
@@ -1146,15 +1141,13 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
             const size_t waves = (size_t)grid * (wg / 64);
             if (pipeline == MPT_PIPE_WAVELOCAL && waves > L.ring_waves) {
                 WaveRings& r = L.ring;
-                hipFree(r.od); hipFree(r.dt); hipFree(r.tl); hipFree(r.ia); hipFree(r.tv);
+                hipFree(r.base);
                 r = WaveRings{};
                 L.ring_waves = 0;
                 const size_t n = waves * MPT_WL_LEVELS * MPT_WL_RING;
-                HIPCHK(hipMalloc(&r.od, n * 16));
-                HIPCHK(hipMalloc(&r.dt, n * 16));
-                HIPCHK(hipMalloc(&r.tl, n * 16));
-                HIPCHK(hipMalloc(&r.ia, n * 16));
-                HIPCHK(hipMalloc(&r.tv, n * 16 + waves * 128 + 1024));  // + room for the MPT_DEBUG_WAVE_TIMES records
+                if (n >= (1ull << 31)) return fail(ctx, MPT_ERR_INVALID_ARG, "too many waves for the ring index (internal)");
+                HIPCHK(hipMalloc(&r.base, 5 * n * 16 + waves * 128 + 1024));  // five arrays + room for the MPT_DEBUG_WAVE_TIMES records
+                r.n = (uint32_t)n;
                 L.ring_waves = waves;
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
@@ -1163,13 +1156,10 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
                     free_ot_rings(L.ot_ring);
                     L.ot_ring_waves = 0;
                     const size_t n = waves * MPT_OT_RINGS * MPT_WL_RING;
+                    if (n >= (1ull << 31)) return fail(ctx, MPT_ERR_INVALID_ARG, "too many waves for the ring index (internal)");
                     OtRings& r = L.ot_ring;
-                    HIPCHK(hipMalloc(&r.od, n * 16));
-                    HIPCHK(hipMalloc(&r.dt, n * 16));
-                    HIPCHK(hipMalloc(&r.tl, n * 16));
-                    HIPCHK(hipMalloc(&r.ia, n * 16));
-                    HIPCHK(hipMalloc(&r.tv, n * 16));
-                    for (auto& p : r.sk) HIPCHK(hipMalloc(&p, n * 16));
+                    HIPCHK(hipMalloc(&r.base, MPT_OT_RING_ARRAYS * n * 16));
+                    r.n = (uint32_t)n;
                     L.ot_ring_waves = waves;
                 }
                 void* args[] = {(void*)&pp, (void*)&accel, (void*)&L.ot_ring, (void*)&ctx->ot_budgets, (void*)&wl_block, (void*)&wl_min, (void*)&wl_div};
@@ -2004,14 +1994,14 @@ extern "C" void mpt_debug_bind(mpt_ctx* ctx) { g_dbg_ctx = ctx; }
 extern "C" int mpt_debug_reset() {   // zero the diagnostics block behind lane 0's rings
     mpt_ctx* ctx = g_dbg_ctx;
     const Lane& L = ctx->lane[0];
-    if (!L.ring.tv) return -1;
+    if (!L.ring.base) return -1;
     const size_t off = L.ring_waves * MPT_WL_LEVELS * MPT_WL_RING;
-    return (int)hipMemset((char*)L.ring.tv + off * 16, 0, L.ring_waves * 128 + 1024);
+    return (int)hipMemset((char*)L.ring.tv() + off * 16, 0, L.ring_waves * 128 + 1024);
 }
 extern "C" int mpt_debug_wave_times(unsigned long long* out, int n) {
     mpt_ctx* ctx = g_dbg_ctx;
     const Lane& L = ctx->lane[0];
     const size_t off = L.ring_waves * MPT_WL_LEVELS * MPT_WL_RING;
-    return (int)hipMemcpy(out, (const char*)L.ring.tv + off * 16, (size_t)n * 128 + 1024, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out, (const char*)L.ring.tv() + off * 16, (size_t)n * 128 + 1024, hipMemcpyDeviceToHost);
 }
 #endif

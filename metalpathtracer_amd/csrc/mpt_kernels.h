@@ -138,30 +138,38 @@ __device__ __forceinline__ bool path_to_pixel(const PassParams& pp, uint32_t pat
 // Fragment.metal:29-42 — seed, sub-pixel jitter, primary ray.
 // (uvx, uvy): the pixel centre in [0,1]^2, Vertex.metal:5-17 — they depend on the pixel only, so k_wavelocal keeps them
 // across the primary steps of one tile (two IEEE divisions less per step)
-__device__ __forceinline__ void pixel_uv(const PassParams& pp, uint32_t px, uint32_t py, float& uvx, float& uvy) {
-    uvx = ((float)px + 0.5f) / pp.W;
-    uvy = ((float)py + 0.5f) / pp.H;
+// The camera as gen_primary reads it: from the kernel arguments (cam_of) or, in k_wavelocal, from a copy in LDS — 14 scalar
+// registers that the persistent step loop does not have to keep alive (or spill) between two primary steps.
+struct CamView {
+    F3 cam, first, vu, vv;
+    float W, H;
+};
+__device__ __forceinline__ CamView cam_of(const PassParams& pp) { return CamView{pp.cam, pp.first, pp.vu, pp.vv, pp.W, pp.H}; }
+__device__ __forceinline__ void pixel_uv(const CamView& cv, uint32_t px, uint32_t py, float& uvx, float& uvy) {
+    uvx = ((float)px + 0.5f) / cv.W;
+    uvy = ((float)py + 0.5f) / cv.H;
 }
-__device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, float uvx, float uvy, uint32_t sample,
+__device__ __forceinline__ void pixel_uv(const PassParams& pp, uint32_t px, uint32_t py, float& uvx, float& uvy) { pixel_uv(cam_of(pp), px, py, uvx, uvy); }
+__device__ __forceinline__ void gen_primary(const PassParams& pp, const CamView& cv, uint32_t px, uint32_t py, float uvx, float uvy, uint32_t sample,
                                             PathState& ps, PathRngDev& g) {
     float xOff, yOff;
     g.pixel = py * pp.width + px;
     g.sample = sample;
     if (pp.sp.rng_mode == 0) {
         uint32_t seed = pp.pixel_seed[g.pixel];
-        xOff = (pcg_float(seed) - 0.5f) / pp.W;
+        xOff = (pcg_float(seed) - 0.5f) / cv.W;
         seed = pcg_hash(seed);
-        yOff = (pcg_float(seed) - 0.5f) / pp.H;
+        yOff = (pcg_float(seed) - 0.5f) / cv.H;
         seed = pcg_hash(seed);
         g.lit_seed = seed;
     } else {
         U4 r = philox4x32_10<true>(g.pixel, sample, 0xFFFFFFFFu, 0u, pp.sp.seed_lo, pp.sp.seed_hi);
-        xOff = (u01(r.x) - 0.5f) / pp.W;
-        yOff = (u01(r.y) - 0.5f) / pp.H;
+        xOff = (u01(r.x) - 0.5f) / cv.W;
+        yOff = (u01(r.y) - 0.5f) / cv.H;
         g.lit_seed = 0;
     }
-    F3 dir = (pp.first + (uvx + xOff) * pp.vu + (uvy + yOff) * pp.vv) - pp.cam;
-    ps.o = pp.cam;
+    F3 dir = (cv.first + (uvx + xOff) * cv.vu + (uvy + yOff) * cv.vv) - cv.cam;
+    ps.o = cv.cam;
     ps.d = normalize3(dir);
     ps.thr = f3(1, 1, 1);
     ps.L = f3(0, 0, 0);
@@ -169,6 +177,10 @@ __device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, u
     ps.bounce = 0;
 }
 
+__device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, float uvx, float uvy, uint32_t sample,
+                                            PathState& ps, PathRngDev& g) {
+    gen_primary(pp, cam_of(pp), px, py, uvx, uvy, sample, ps, g);
+}
 __device__ __forceinline__ void gen_primary(const PassParams& pp, uint32_t px, uint32_t py, uint32_t sample,
                                             PathState& ps, PathRngDev& g) {
     float uvx, uvy;
@@ -467,6 +479,9 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 #define MPT_WL_LEVELS 5u
 #endif
 #define MPT_WL_RING 512u       // records per ring
+#define MPT_LDS_MATS_N 32u     // materials staged in LDS (= MPT_LDS_MATS of mpt_hip.hip): the configuration block of k_wavelocal / k_ordered starts behind them
+#define MPT_LDS_CFG_F4 16u     // ... and is this many float4 long (256 bytes): camera in float4 0..3, then 32 words (budgets 0..15, claim parameters 16..19).
+                               // The host reserves it (MPT_LDS_EXTRA, ordered_views): k_ordered's stacks start right behind it.
 #define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
 #define MPT_WL_NO_BUDGET 0x7FFFFFFFu  // budgets at or above this mean "run to completion"
 // Ring record (round 4, "the traffic diet"): 48 bytes that every ray needs — od, dt, ia — and 16 more (tl: the light gathered so
@@ -479,12 +494,14 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 #define MPT_WL_DIET 1
 #endif
 #define MPT_RING_HAS_LIGHT 0x100u
-struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING]
-    float4* od;                // (o.xyz, d.x)
-    float4* dt;                // (d.y, d.z, thr.r, thr.g)
-    float4* tl;                // MPT_WL_DIET: (L.rgb, L.a), written only with MPT_RING_HAS_LIGHT; else (thr.b, L.rgb)
-    uint4* ia;                 // MPT_WL_DIET: (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT); else (path, L.a bits, pixel, sample | bounce << 27)
-    uint4* tv;                 // rings >= 1: (next node, best t bits, best primitive, 0)
+struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING] records in five arrays of 16-byte fields, ONE allocation: the kernel
+    float4* base;              // keeps one base pointer and the array length in scalar registers instead of five pointers
+    uint32_t n;                // records per array = n_waves * MPT_WL_LEVELS * MPT_WL_RING
+    __host__ __device__ float4* od() const { return base; }                        // (o.xyz, d.x)
+    __host__ __device__ float4* dt() const { return base + n; }                    // (d.y, d.z, thr.r, thr.g)
+    __host__ __device__ float4* tl() const { return base + 2u * (size_t)n; }       // MPT_WL_DIET: (L.rgb, L.a), written only with MPT_RING_HAS_LIGHT; else (thr.b, L.rgb)
+    __host__ __device__ uint4* ia() const { return (uint4*)(base + 3u * (size_t)n); }  // MPT_WL_DIET: (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT); else (path, L.a bits, pixel, sample | bounce << 27)
+    __host__ __device__ uint4* tv() const { return (uint4*)(base + 4u * (size_t)n); }  // rings >= 1: (next node, best t bits, best primitive, 0)
 };
 // what a push writes / a pop reads (both pipelines' rings use the same record)
 __device__ __forceinline__ bool ring_has_light(const PathState& ps) {
@@ -495,20 +512,20 @@ __device__ __forceinline__ uint32_t sample_of_path(const PassParams& pp, uint32_
     return pp.sample_begin + (pp.s_shift != 0xFFu ? chunk & (pp.S - 1u) : chunk % pp.S);
 }
 __device__ __forceinline__ void ring_push(const WaveRings& ring, uint32_t at, const PathState& ps, const PathRngDev& g) {
-    ring.od[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-    ring.dt[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+    ring.od()[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    ring.dt()[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
 #if MPT_WL_DIET
     const bool lit = ring_has_light(ps);
-    ring.ia[at] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
-    if (lit) ring.tl[at] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
+    ring.ia()[at] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
+    if (lit) ring.tl()[at] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
 #else
-    ring.tl[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-    ring.ia[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+    ring.tl()[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+    ring.ia()[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
 #endif
 }
 __device__ __forceinline__ void ring_pop(const PassParams& pp, const WaveRings& ring, uint32_t at, PathState& ps, PathRngDev& g) {
-    const float4 a = ring.od[at], b = ring.dt[at];
-    const uint4 ia = ring.ia[at];
+    const float4 a = ring.od()[at], b = ring.dt()[at];
+    const uint4 ia = ring.ia()[at];
     ps.o = f3(a.x, a.y, a.z);
     ps.d = f3(a.w, b.x, b.y);
 #if MPT_WL_DIET
@@ -520,12 +537,12 @@ __device__ __forceinline__ void ring_pop(const PassParams& pp, const WaveRings& 
     ps.L = f3(0.0f, 0.0f, 0.0f);
     ps.La = 0.0f;
     if ((ia.w & MPT_RING_HAS_LIGHT) != 0u) {
-        const float4 cc = ring.tl[at];
+        const float4 cc = ring.tl()[at];
         ps.L = f3(cc.x, cc.y, cc.z);
         ps.La = cc.w;
     }
 #else
-    const float4 cc = ring.tl[at];
+    const float4 cc = ring.tl()[at];
     ps.thr = f3(b.z, b.w, cc.x);
     ps.L = f3(cc.y, cc.z, cc.w);
     ps.La = __uint_as_float(ia.y);
@@ -537,6 +554,46 @@ __device__ __forceinline__ void ring_pop(const PassParams& pp, const WaveRings& 
     g.lit_seed = 0;
     if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
 }
+// Ring 0 as a ring of HITS (round 4, -DMPT_WL_HITRING=0 for round 3's order of work).  Round 3 shaded a ray where its closest hit
+// was found: in a step of 64 rays about half hit a surface and half the sky, so the 250-instruction hit branch ran at half
+// width — 8 wave-instructions per hit.  Now the step that finds a hit pushes the HIT (the ray, its t and primitive) to ring 0,
+// and the step that pops 64 hits shades all of them first, at full width, and traces the 64 bounce rays right away: the same
+// one ring hop per bounce as before, the same 48 (+ 16) bytes (t takes the place of the pixel index, which is recomputed from
+// the path id, and the primitive shares a word with the bounce count), and every ray sees the same arithmetic in the same order.
+#ifndef MPT_WL_HITRING
+#define MPT_WL_HITRING 1
+#endif
+#if MPT_WL_HITRING && !MPT_WL_DIET
+#error "MPT_WL_HITRING needs the MPT_WL_DIET record"
+#endif
+// record: od, dt as above; ia = (thr.b bits, path, t bits | light flag in the sign bit (t > 0), primitive | bounce << 27); tl as above
+__device__ __forceinline__ void ring_push_hit(const WaveRings& ring, uint32_t at, const PathState& ps, float t, uint32_t prim) {
+    ring.od()[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    ring.dt()[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+    const bool lit = ring_has_light(ps);
+    ring.ia()[at] = make_uint4(__float_as_uint(ps.thr.z), ps.path, (__float_as_uint(t) & 0x7FFFFFFFu) | (lit ? 0x80000000u : 0u),
+                               (prim & 0x07FFFFFFu) | (ps.bounce << 27));
+    if (lit) ring.tl()[at] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
+}
+__device__ __forceinline__ void ring_pop_hit(const WaveRings& ring, uint32_t at, PathState& ps, float& t, int& prim) {
+    const float4 a = ring.od()[at], b = ring.dt()[at];
+    const uint4 ia = ring.ia()[at];
+    ps.o = f3(a.x, a.y, a.z);
+    ps.d = f3(a.w, b.x, b.y);
+    ps.thr = f3(b.z, b.w, __uint_as_float(ia.x));
+    ps.path = ia.y;
+    t = __uint_as_float(ia.z & 0x7FFFFFFFu);
+    prim = (int)(ia.w & 0x07FFFFFFu);
+    ps.bounce = ia.w >> 27;
+    ps.L = f3(0.0f, 0.0f, 0.0f);
+    ps.La = 0.0f;
+    if ((ia.z & 0x80000000u) != 0u) {
+        const float4 cc = ring.tl()[at];
+        ps.L = f3(cc.x, cc.y, cc.z);
+        ps.La = cc.w;
+    }
+}
+
 struct WaveBudgets {
     uint32_t b[MPT_WL_LEVELS]; // box-test loop trips granted per step of ring k (last entry unused: unlimited)
     uint32_t min_active[MPT_WL_LEVELS];  // a step of ring k ends early once fewer lanes than this are still traversing
@@ -560,21 +617,42 @@ template <bool COUNT, bool ALL_LDS>
 __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) void k_wavelocal(PassParams pp, WaveRings ring, WaveBudgets budgets,
                                                                  uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_nodes_raw[];
+    // what only some steps need goes to LDS, behind the scene image (the 256-byte descriptor area of MPT_LDS_EXTRA), instead of
+    // living in scalar registers across the whole step loop: the camera (14 words, primary steps) and the ring budgets (10 words,
+    // ring steps).  The loop needs more scalar registers than the 102 a wave has; every value kept out of it is one spill less.
+    const uint32_t cfg_off = pp.scene.lds_mat_off + 2u * MPT_LDS_MATS_N;   // in float4 units
+    if (threadIdx.x == 0) {
+        lds_nodes_raw[cfg_off + 0] = make_float4(pp.cam.x, pp.cam.y, pp.cam.z, pp.W);
+        lds_nodes_raw[cfg_off + 1] = make_float4(pp.first.x, pp.first.y, pp.first.z, pp.H);
+        lds_nodes_raw[cfg_off + 2] = make_float4(pp.vu.x, pp.vu.y, pp.vu.z, 0.0f);
+        lds_nodes_raw[cfg_off + 3] = make_float4(pp.vv.x, pp.vv.y, pp.vv.z, 0.0f);
+        uint32_t* w = (uint32_t*)(lds_nodes_raw + cfg_off + 4);
+        for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) {
+            w[k] = budgets.b[k];
+            w[8u + k] = budgets.min_active[k];
+        }
+        // ... and what only a CLAIM of path ids needs (words 16..19 of the block's 32: static_assert below)
+        static_assert(4u * (MPT_LDS_CFG_F4 - 4u) >= 20u, "configuration block too small");
+        w[16] = wl_block;
+        w[17] = wl_min;
+        w[18] = wl_div * (((uint32_t)(gridDim.x * (blockDim.x >> 6)) + MPT_NGROUP - 1u) / MPT_NGROUP);   // wl_div * waves per claim range
+        w[19] = pp.desc->total_paths / (pp.S * 64u);                                                   // this rank's tiles
+    }
     stage_nodes(pp.scene, lds_nodes_raw);
     MPT_CLOCK_BEGIN();
     const LdsNodes lds_nodes = (LdsNodes)lds_nodes_raw;
+    const __attribute__((address_space(3))) uint32_t* lds_cfg_u32 = (const __attribute__((address_space(3))) uint32_t*)(lds_nodes + cfg_off + 4u);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total_paths = pp.desc->total_paths;
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+#ifdef MPT_DEBUG_WAVE_TIMES
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+#endif
     const uint32_t wbase = wave_id * (MPT_WL_LEVELS * MPT_WL_RING);
     const uint32_t M = MPT_WL_RING - 1u;
     uint32_t head[MPT_WL_LEVELS], cnt[MPT_WL_LEVELS];  // wave-uniform ring state (fully unrolled accesses)
 #pragma unroll
     for (uint32_t k = 0; k < MPT_WL_LEVELS; ++k) head[k] = cnt[k] = 0;
     uint32_t cur = 0, end = 0;     // wave-uniform private range of path ids (multiples of 64)
-    const uint32_t n_tiles = total_paths / (pp.S * 64u);  // this rank's tiles
-    const uint32_t waves_per_group = (n_waves + MPT_NGROUP - 1u) / MPT_NGROUP;
     uint32_t grp = blockIdx.x & (MPT_NGROUP - 1u);     // range this wave currently claims from
     uint32_t seen = 0;                                 // cursor value (virtual index) at this wave's previous claim
     bool exhausted = false;
@@ -609,14 +687,15 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 uint32_t k = 0, blk = 0, rend = 0;
                 bool got = false;
                 if (lane == 0) {
+                    const uint32_t c_block = lds_cfg_u32[16], c_min = lds_cfg_u32[17], c_div = lds_cfg_u32[18], c_tiles = lds_cfg_u32[19];   // (claim parameters: from LDS)
                     for (uint32_t t = 0; t < MPT_NGROUP && !got; ++t) {
-                        const uint32_t re = range_paths(n_tiles, pp.S, grp);
+                        const uint32_t re = range_paths(c_tiles, pp.S, grp);
                         const uint32_t left = seen < re ? re - seen : 0u;
-                        blk = (left / (wl_div * waves_per_group)) & ~63u;
-                        blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
+                        blk = (left / c_div) & ~63u;
+                        blk = blk < c_min ? c_min : (blk > c_block ? c_block : blk);
                         // a range entered by stealing is near its end but `seen` knows nothing about it yet: the first
                         // claim there is the minimum (it returns the cursor, which sizes the following ones)
-                        if (t > 0u) blk = wl_min;
+                        if (t > 0u) blk = c_min;
                         k = atomicAdd(&pp.ctr[MPT_CTR_CURSOR(grp)], blk);
                         if (k < re) {
                             got = true;
@@ -677,6 +756,11 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         int best_prim = -1;
         uint32_t budget = 0xFFFFFFFFu, min_active = 0u;
         bool fresh = false;  // this lane starts a new closest-hit query (primary ray or ring-0 record)
+#if MPT_WL_HITRING
+        bool need_shade = false;   // this lane popped a hit from ring 0
+        float hit_t = 0.0f;
+        int hit_prim = -1;
+#endif
         if (level < 0) {
             fresh = true;
             // 64 new paths = one 8x8 pixel tile at one sample index: everything about the tile is wave-uniform, and its
@@ -699,9 +783,19 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             }
             ps.path = pchunk * 64u + lane;
             const uint32_t px = (tile_xy_cached & 0xFFFFu) * 8u + (lane & 7u), py = (tile_xy_cached >> 16) * 8u + (lane >> 3);
-            if (new_tile) pixel_uv(pp, px, py, uvx_cached, uvy_cached);
+            CamView cv;
+            {
+                const v4f c0 = lds_nodes[cfg_off], c1 = lds_nodes[cfg_off + 1u], c2 = lds_nodes[cfg_off + 2u], c3 = lds_nodes[cfg_off + 3u];
+                cv.cam = f3(c0.x, c0.y, c0.z);
+                cv.first = f3(c1.x, c1.y, c1.z);
+                cv.vu = f3(c2.x, c2.y, c2.z);
+                cv.vv = f3(c3.x, c3.y, c3.z);
+                cv.W = c0.w;
+                cv.H = c1.w;
+            }
+            if (new_tile) pixel_uv(cv, px, py, uvx_cached, uvy_cached);
             if (px < pp.width && py < pp.height) {
-                gen_primary(pp, px, py, uvx_cached, uvy_cached, pp.sample_begin + sidx, ps, g);
+                gen_primary(pp, cv, px, py, uvx_cached, uvy_cached, pp.sample_begin + sidx, ps, g);
                 valid = true;
                 n_paths++;
             }
@@ -725,15 +819,16 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                     my_off = cnt[k] - tk + (lane - assigned);  // newest records first: they are still in L2
 #endif
                 }
-                if (level == k) {
-                    budget = budgets.b[k];
-                    min_active = budgets.min_active[k];
-                }
+                (void)k;
 #ifdef MPT_WL_FIFO
                 head[k] = (head[k] + tk) & M;
 #endif
                 cnt[k] -= tk;
                 assigned += tk;
+            }
+            if (level < (int)MPT_WL_LEVELS) {   // (a ring step: its budget and its minimum of working lanes, from the LDS copy)
+                budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_cfg_u32[level]);
+                min_active = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_cfg_u32[8 + level]);
             }
             // merged drain step: no trip budget, but the stragglers of a step (fewer than a third of the lanes it
             // started with) go back to the last ring and are traced together once the rest is gone (4.76 -> 4.54 ms
@@ -742,8 +837,13 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             if (take) {
                 const uint32_t at = wbase + my_ring * MPT_WL_RING + my_off;
                 uint4 tv = make_uint4(0u, 0u, 0u, 0u);
-                if (my_ring > 0u) tv = ring.tv[at];   // (issued with the record's other loads, ahead of ring_pop's conditional one)
+                if (my_ring > 0u) tv = ring.tv()[at];   // (issued with the record's other loads, ahead of ring_pop's conditional one)
+#if MPT_WL_HITRING
+                ring_pop_hit(ring, at, ps, hit_t, hit_prim);
+                need_shade = my_ring == 0u;
+#else
                 ring_pop(pp, ring, at, ps, g);
+#endif
                 if (my_ring > 0u) {
                     node = tv.x;
                     best_t = __uint_as_float(tv.y);
@@ -754,6 +854,21 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 valid = true;
             }
         }
+#if MPT_WL_HITRING
+        // ---- the hits popped from ring 0 are shaded first — all 64 lanes of a ring-0 step — and leave their bounce rays in `ps` ------
+        if (need_shade) {
+            uint32_t px, py, sidx;
+            path_to_pixel(pp, ps.path, px, py, sidx);
+            g.pixel = py * pp.width + px;
+            g.sample = pp.sample_begin + sidx;
+            g.lit_seed = 0;
+            if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+            if (!shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, hit_t, hit_prim)) {   // the path ends here (depth limit, material guard)
+                store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+                valid = false;
+            }
+        }
+#endif
         // the last ring never has a budget; a ring whose budget is "none" runs the plain (unsynchronised) loop
         // (the last ring has no trip budget; with a min_active rule its stragglers go back on top of the same ring)
         const bool budgeted = level >= 0 && (level < (int)MPT_WL_LEVELS || min_active != 0u) &&
@@ -776,7 +891,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             MPT_TOC(reg_trace, tic_);
 #ifdef MPT_DEBUG_WAVE_TIMES
             if (COUNT) {  // per-level divergence diagnostics: [level + 1][steps, box trips, box lane work, prim trips, prim lane work]
-                unsigned long long* lv = (unsigned long long*)(ring.tv + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING) +
+                unsigned long long* lv = (unsigned long long*)(ring.tv() + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING) +
                                          16ull * n_waves + 8ull * (unsigned)(level + 1);
                 if (first_active_lane()) atomicAdd(lv + 0, 1ull);
                 // the per-wave trip counters live in whichever lane was first active at the time: sum over lanes
@@ -790,9 +905,17 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
             }
 #endif
             if (done) {
+#if MPT_WL_HITRING
+                alive = best_prim >= 0;   // a hit: to ring 0 as it is, shaded by the step that pops it
+                if (!alive) {             // the sky ends the path (PathTracing.h:225-232)
+                    shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, -1);
+                    store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+                }
+#else
                 alive = shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, best_prim);
                 if (!alive)
                     store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+#endif
             } else {
                 parked = true;
             }
@@ -802,9 +925,13 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
         if (am != 0ull) {  // survivors are fresh rays -> ring 0
             if (alive) {
                 const uint32_t at = wbase + ((head[0] + cnt[0] + wave_rank(am)) & M);
+#if MPT_WL_HITRING
+                ring_push_hit(ring, at, ps, best_t, (uint32_t)best_prim);
+#else
                 ring_push(ring, at, ps, g);
-#ifdef MPT_DIET_RINGPLUS   // (ring.tv of ring 0 is never read: fresh rays carry no traversal state)
-                ring.tv[at] = make_uint4(ps.path, 0u, 0u, 0u);
+#endif
+#ifdef MPT_DIET_RINGPLUS   // (ring.tv() of ring 0 is never read: fresh rays carry no traversal state)
+                ring.tv()[at] = make_uint4(ps.path, 0u, 0u, 0u);
 #endif
             }
             cnt[0] += (uint32_t)__popcll(am);
@@ -819,8 +946,12 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
                 }
             if (parked) {
                 const uint32_t at = wbase + (uint32_t)park_ring * MPT_WL_RING + ((h + c + wave_rank(pm)) & M);
+#if MPT_WL_HITRING
+                ring_push_hit(ring, at, ps, 0.0f, 0u);   // (a parked ray: its traversal state is in tv)
+#else
                 ring_push(ring, at, ps, g);
-                ring.tv[at] = make_uint4(node, __float_as_uint(best_t), (uint32_t)best_prim, 0u);
+#endif
+                ring.tv()[at] = make_uint4(node, __float_as_uint(best_t), (uint32_t)best_prim, 0u);
             }
 #pragma unroll
             for (int k = 1; k < (int)MPT_WL_LEVELS; ++k)
@@ -834,7 +965,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
     }
 #ifdef MPT_DEBUG_WAVE_TIMES  // diagnostics build: per-wave (start, cursor exhausted, end) timestamps, 100 MHz ticks
     if (lane == 0) {
-        unsigned long long* dbg = (unsigned long long*)(ring.tv + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING);
+        unsigned long long* dbg = (unsigned long long*)(ring.tv() + (size_t)n_waves * MPT_WL_LEVELS * MPT_WL_RING);
         dbg[8 * wave_id] = t_start;
         dbg[8 * wave_id + 1] = t_exh;
         dbg[8 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();

@@ -103,14 +103,17 @@ __device__ __forceinline__ void ot_flush_walk_times(const WorkCount& wc, uint32_
 #define OT_TOC(r) do { } while (0)
 #endif
 
-struct OtRings {              // [n_waves][MPT_OT_RINGS][MPT_WL_RING] records, struct of arrays of 16-byte fields
-    float4* od;               // (o.xyz, d.x)
-    float4* dt;               // (d.y, d.z, thr.r, thr.g)
-    float4* tl;               // as WaveRings (mpt_kernels.h): with MPT_WL_DIET (L.rgb, L.a), written only for rays that have gathered light
-    uint4* ia;                // ... and (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT)
-    uint4* tv;                // rings M, H: (best t bits, best primitive, next node / leaf of the walk, stack entries)
-    uint4* sk[MPT_OT_PARK / 2u];  // rings M: the walk's stack, two (key, ref) entries per field
+struct OtRings {              // [n_waves][MPT_OT_RINGS][MPT_WL_RING] records, struct of arrays of 16-byte fields; ONE allocation (one base
+    float4* base;             // pointer + the array length in scalar registers instead of nine pointers)
+    uint32_t n;               // records per array
+    __host__ __device__ float4* od() const { return base; }                               // (o.xyz, d.x)
+    __host__ __device__ float4* dt() const { return base + n; }                           // (d.y, d.z, thr.r, thr.g)
+    __host__ __device__ float4* tl() const { return base + 2u * (size_t)n; }              // as WaveRings (mpt_kernels.h): with MPT_WL_DIET (L.rgb, L.a), only for rays that have gathered light
+    __host__ __device__ uint4* ia() const { return (uint4*)(base + 3u * (size_t)n); }     // ... and (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT)
+    __host__ __device__ uint4* tv() const { return (uint4*)(base + 4u * (size_t)n); }     // rings M: (best t bits, best primitive, next node / leaf of the walk, stack entries)
+    __host__ __device__ uint4* sk(uint32_t k) const { return (uint4*)(base + (5u + k) * (size_t)n); }  // rings M: the walk's stack, two (key, ref) entries per field
 };
+#define MPT_OT_RING_ARRAYS (5u + MPT_OT_PARK / 2u)
 struct OtBudgets {
     uint32_t trips[MPT_OT_MLEVELS];       // node-loop trips a step of ring M_k may make (the last level: unlimited)
     uint32_t min_active[MPT_OT_MLEVELS];  // ... and it ends once fewer lanes than this are still walking
@@ -695,21 +698,39 @@ template <bool COUNT, bool ALL_LDS>
 __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassParams pp, AccelDev ac, OtRings ring, OtBudgets budgets,
                                                                           uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_raw[];
+    // camera and budgets live in LDS (the MPT_LDS_CFG_F4 block behind the material table), not in scalar registers across the step loop
+    // (as in k_wavelocal, mpt_kernels.h)
+    const uint32_t cfg_off = pp.scene.lds_mat_off + 2u * MPT_LDS_MATS_N;
+    if (threadIdx.x == 0) {
+        lds_raw[cfg_off + 0] = make_float4(pp.cam.x, pp.cam.y, pp.cam.z, pp.W);
+        lds_raw[cfg_off + 1] = make_float4(pp.first.x, pp.first.y, pp.first.z, pp.H);
+        lds_raw[cfg_off + 2] = make_float4(pp.vu.x, pp.vu.y, pp.vu.z, 0.0f);
+        lds_raw[cfg_off + 3] = make_float4(pp.vv.x, pp.vv.y, pp.vv.z, 0.0f);
+        uint32_t* w = (uint32_t*)(lds_raw + cfg_off + 4);
+        for (uint32_t k = 0; k < MPT_OT_MLEVELS; ++k) {
+            w[k] = budgets.trips[k];
+            w[8u + k] = budgets.min_active[k];
+        }
+        w[15] = budgets.inplace_min;
+        // ... and what only a CLAIM of path ids needs (words 16..19 of the block's 32; the stacks start behind the block: ordered_views)
+        static_assert(4u * (MPT_LDS_CFG_F4 - 4u) >= 20u, "configuration block too small");
+        w[16] = wl_block;
+        w[17] = wl_min;
+        w[18] = wl_div * (((uint32_t)(gridDim.x * (blockDim.x >> 6)) + MPT_NGROUP - 1u) / MPT_NGROUP);   // wl_div * waves per claim range
+        w[19] = pp.desc->total_paths / (pp.S * 64u);                                                   // this rank's tiles
+    }
     ot_stage(pp.scene, ac, lds_raw);
     MPT_CLOCK_BEGIN();
     const LdsNodes lds = (LdsNodes)lds_raw;
+    const __attribute__((address_space(3))) uint32_t* lds_cfg_u32 = (const __attribute__((address_space(3))) uint32_t*)(lds + cfg_off + 4u);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total_paths = pp.desc->total_paths;
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const OtStack st = ot_stack(ac, lds_raw, wave_id);
     const uint32_t wbase = wave_id * (MPT_OT_RINGS * MPT_WL_RING);
     uint32_t cnt[MPT_OT_RINGS];   // wave-uniform ring fills (the rings are stacks: newest first)
 #pragma unroll
     for (uint32_t k = 0; k < MPT_OT_RINGS; ++k) cnt[k] = 0u;
     uint32_t cur = 0, end = 0;
-    const uint32_t n_tiles = total_paths / (pp.S * 64u);
-    const uint32_t waves_per_group = (n_waves + MPT_NGROUP - 1u) / MPT_NGROUP;
     uint32_t grp = blockIdx.x & (MPT_NGROUP - 1u);
     uint32_t seen = 0;
     bool exhausted = false;
@@ -742,12 +763,13 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 uint32_t k = 0, blk = 0, rend = 0;
                 bool got = false;
                 if (lane == 0) {
+                    const uint32_t c_block = lds_cfg_u32[16], c_min = lds_cfg_u32[17], c_div = lds_cfg_u32[18], c_tiles = lds_cfg_u32[19];   // (claim parameters: from LDS)
                     for (uint32_t t = 0; t < MPT_NGROUP && !got; ++t) {
-                        const uint32_t re = range_paths(n_tiles, pp.S, grp);
+                        const uint32_t re = range_paths(c_tiles, pp.S, grp);
                         const uint32_t left = seen < re ? re - seen : 0u;
-                        blk = (left / (wl_div * waves_per_group)) & ~63u;
-                        blk = blk < wl_min ? wl_min : (blk > wl_block ? wl_block : blk);
-                        if (t > 0u) blk = wl_min;
+                        blk = (left / c_div) & ~63u;
+                        blk = blk < c_min ? c_min : (blk > c_block ? c_block : blk);
+                        if (t > 0u) blk = c_min;
                         k = atomicAdd(&pp.ctr[MPT_CTR_CURSOR(grp)], blk);
                         if (k < re) {
                             got = true;
@@ -811,7 +833,17 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             ps.path = pchunk * 64u + lane;
             const uint32_t px = (tile_xy_cached & 0xFFFFu) * 8u + (lane & 7u), py = (tile_xy_cached >> 16) * 8u + (lane >> 3);
             if (px < pp.width && py < pp.height) {
-                gen_primary(pp, px, py, pp.sample_begin + sidx, ps, g);
+                CamView cv;
+                const v4f c0 = lds[cfg_off], c1 = lds[cfg_off + 1u], c2 = lds[cfg_off + 2u], c3 = lds[cfg_off + 3u];
+                cv.cam = f3(c0.x, c0.y, c0.z);
+                cv.first = f3(c1.x, c1.y, c1.z);
+                cv.vu = f3(c2.x, c2.y, c2.z);
+                cv.vv = f3(c3.x, c3.y, c3.z);
+                cv.W = c0.w;
+                cv.H = c1.w;
+                float uvx, uvy;
+                pixel_uv(cv, px, py, uvx, uvy);
+                gen_primary(pp, cv, px, py, uvx, uvy, pp.sample_begin + sidx, ps, g);
                 valid = true;
                 n_paths++;
             }
@@ -827,13 +859,13 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             for (uint32_t k = 0; k < MPT_OT_RINGS; ++k)
                 if (k == kind) cnt[k] = c - take;
             if (valid) {
-                const float4 a = ot_pop4(ring.od + at), b = ot_pop4(ring.dt + at);
+                const float4 a = ot_pop4(ring.od() + at), b = ot_pop4(ring.dt() + at);
                 ps.o = f3(a.x, a.y, a.z);
                 ps.d = f3(a.w, b.x, b.y);
                 ps.thr.x = b.z;
                 ps.thr.y = b.w;
                 if (kind >= MPT_OT_RING_M) {
-                    const uint4 tv = ot_pop4u(ring.tv + at);
+                    const uint4 tv = ot_pop4u(ring.tv() + at);
                     T = __uint_as_float(tv.x);
                     W = (int)tv.y;
                     walk_cur = tv.z;
@@ -849,7 +881,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
                     if (2u * k >= deepest) break;
                     if (valid && walk_sp > 2u * k) {
-                        const uint4 e = ot_pop4u(ring.sk[k] + at);
+                        const uint4 e = ot_pop4u(ring.sk(k) + at);
                         st.lds[(2u * k) * 64u] = v2u{e.x, e.y};
                         st.lds[(2u * k + 1u) * 64u] = v2u{e.z, e.w};
                     }
@@ -859,7 +891,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         // the rest of a record is not needed by the tree walk: ring M steps load it afterwards
         auto load_rest = [&]() {
 #if MPT_WL_DIET   // the 48 + 16-byte record of mpt_kernels.h (WaveRings): tl only for the rays that have gathered light
-            const uint4 ia = ot_pop4u(ring.ia + at);
+            const uint4 ia = ot_pop4u(ring.ia() + at);
             ps.thr.z = __uint_as_float(ia.x);
             ps.path = ia.y;
             g.pixel = ia.z;
@@ -868,13 +900,13 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             ps.L = f3(0.0f, 0.0f, 0.0f);
             ps.La = 0.0f;
             if ((ia.w & MPT_RING_HAS_LIGHT) != 0u) {
-                const float4 cc = ot_pop4(ring.tl + at);
+                const float4 cc = ot_pop4(ring.tl() + at);
                 ps.L = f3(cc.x, cc.y, cc.z);
                 ps.La = cc.w;
             }
 #else
-            const float4 cc = ot_pop4(ring.tl + at);
-            const uint4 ia = ot_pop4u(ring.ia + at);
+            const float4 cc = ot_pop4(ring.tl() + at);
+            const uint4 ia = ot_pop4u(ring.ia() + at);
             ps.thr.z = cc.x;
             ps.L = f3(cc.y, cc.z, cc.w);
             ps.La = __uint_as_float(ia.y);
@@ -917,7 +949,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             }
             // most of the wave has to walk the tree: do it now, as a step of ring M0 would, and save those rays the trip
             // through the ring (80 bytes written and read back per ray)
-            if ((uint32_t)__popcll(__ballot(dest == MPT_OT_RING_M)) >= budgets.inplace_min) {
+            if ((uint32_t)__popcll(__ballot(dest == MPT_OT_RING_M)) >= (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_cfg_u32[15])) {
                 walk_kind = MPT_OT_RING_M;
                 walking = dest == MPT_OT_RING_M;
                 if (walking) dest = MPT_OT_NONE;
@@ -932,12 +964,8 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             // ---- closest-first walk, continued for this ring's budget of node-loop trips ------------------------------
             bool tie = false, done;
             uint32_t budget = 0u, min_active = 0u;
-#pragma unroll
-            for (uint32_t k = 0; k < MPT_OT_MLEVELS; ++k)
-                if (walk_kind == MPT_OT_RING_M + k) {
-                    budget = budgets.trips[k];
-                    min_active = budgets.min_active[k];
-                }
+            budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_cfg_u32[walk_kind - MPT_OT_RING_M]);
+            min_active = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_cfg_u32[8u + walk_kind - MPT_OT_RING_M]);
             // (the drain walks to the end: parking a handful of rays again and again does not pay)
             if (!exhausted && (walk_kind + 1u < MPT_OT_RINGS || min_active != 0u))
                 done = ot_walk<COUNT, true, ALL_LDS>(ac, pp.scene, lds, st, ps.o, ps.d, r, walk_cur, walk_sp, T, W, tie, walk_lost,
@@ -994,28 +1022,28 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 cnt[k] += (uint32_t)__popcll(m);
             }
             if (dest != MPT_OT_NONE) {
-                ring.od[to] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                ring.dt[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+                ring.od()[to] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+                ring.dt()[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
 #if MPT_WL_DIET
                 {
                     const bool lit = ring_has_light(ps);
-                    ring.ia[to] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
-                    if (lit) ring.tl[to] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
+                    ring.ia()[to] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
+                    if (lit) ring.tl()[to] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
                 }
 #else
-                ring.tl[to] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia[to] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
+                ring.tl()[to] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
+                ring.ia()[to] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
 #endif
                 if (dest >= MPT_OT_RING_M) {
                     // a ray parked by a top test starts its walk at the root (walk_cur = 0, walk_sp = 0 there)
-                    ring.tv[to] = make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,
+                    ring.tv()[to] = make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,
                                              walk_sp | (walk_lost ? 0x40000000u : 0u) | (walk_again ? 0x80000000u : 0u));
                     if (walk_kind != MPT_OT_NONE) {   // (walk_sp = 0 for a ray that has not started)
 #pragma unroll
                         for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
                             if (walk_sp > 2u * k) {
                                 const v2u e0 = st.lds[(2u * k) * 64u], e1 = st.lds[(2u * k + 1u) * 64u];
-                                ring.sk[k][to] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+                                ring.sk(k)[to] = make_uint4(e0.x, e0.y, e1.x, e1.y);
                             }
                         }
                     }
