@@ -69,6 +69,16 @@
 #define MPT_OT_OCT 0
 #endif
 #define MPT_OT_NR (MPT_OT_OCT ? 8u : 1u)  // fresh-ray rings
+// Ring R as a ring of HITS (round 4; as ring 0 of k_wavelocal, mpt_kernels.h MPT_WL_HITRING): a step that has a ray's final closest
+// hit pushes the hit (ray, t, primitive) to ring R instead of shading it at whatever width the step happens to have — the always-list
+// sphere hits of a top test, the finished walks of a ring-M step, the re-traced rays of ring E — and the step that pops 64 hits
+// shades them all at full width, then runs the top test on the 64 bounce rays.  Same number of ring hops, same record size.
+#ifndef MPT_OT_HITRING
+#define MPT_OT_HITRING 1
+#endif
+#if MPT_OT_HITRING && (!MPT_WL_DIET || MPT_OT_OCT)
+#error "MPT_OT_HITRING needs the MPT_WL_DIET record and one fresh-ray ring"
+#endif
 #define MPT_OT_RINGS (MPT_OT_NR + 1u + MPT_OT_MLEVELS) // R (x NR) fresh rays, E reference-order walk, M0.. rays walking the tree
 #define MPT_OT_PARK 8u                    // stack entries a parked ray takes along (>= the LDS stack depth)
 #ifndef MPT_OT_EARLY
@@ -890,7 +900,24 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         }
         // the rest of a record is not needed by the tree walk: ring M steps load it afterwards
         auto load_rest = [&]() {
-#if MPT_WL_DIET   // the 48 + 16-byte record of mpt_kernels.h (WaveRings): tl only for the rays that have gathered light
+#if MPT_OT_HITRING   // ia = (thr.b bits, path, t bits | light flag in the sign bit, primitive | bounce << 27): t / primitive = the hit of a ring-R record
+            const uint4 ia = ot_pop4u(ring.ia() + at);
+            ps.thr.z = __uint_as_float(ia.x);
+            ps.path = ia.y;
+            ps.bounce = ia.w >> 27;
+            if (kind < MPT_OT_RING_E) {
+                T = __uint_as_float(ia.z & 0x7FFFFFFFu);
+                W = (int)(ia.w & 0x07FFFFFFu);
+            }
+            ps.L = f3(0.0f, 0.0f, 0.0f);
+            ps.La = 0.0f;
+            if ((ia.z & 0x80000000u) != 0u) {
+                const float4 cc = ot_pop4(ring.tl() + at);
+                ps.L = f3(cc.x, cc.y, cc.z);
+                ps.La = cc.w;
+            }
+            return;
+#elif MPT_WL_DIET   // the 48 + 16-byte record of mpt_kernels.h (WaveRings): tl only for the rays that have gathered light
             const uint4 ia = ot_pop4u(ring.ia() + at);
             ps.thr.z = __uint_as_float(ia.x);
             ps.path = ia.y;
@@ -919,6 +946,23 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
         };
         if (valid && kind != MPT_OT_NONE && kind < MPT_OT_RING_M) load_rest();
+#if MPT_OT_HITRING
+        // ---- the hits popped from ring R are shaded first — all 64 lanes of the step — and leave their bounce rays in `ps` ------------
+        if (valid && kind != MPT_OT_NONE && kind < MPT_OT_RING_E) {
+            uint32_t px, py, sidx;
+            path_to_pixel(pp, ps.path, px, py, sidx);
+            g.pixel = py * pp.width + px;
+            g.sample = pp.sample_begin + sidx;
+            g.lit_seed = 0;
+            if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
+            if (!shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W)) {   // the path ends here (depth limit, material guard)
+                store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+                valid = false;
+            }
+            T = INFINITY;
+            W = -1;
+        }
+#endif
         OT_TOC(1);
 #ifdef MPT_OT_TIMES
         const uint32_t ot_slot = kind == MPT_OT_NONE ? 2u + MPT_OT_MLEVELS : kind < MPT_OT_RING_E ? 0u : kind - MPT_OT_RING_E + 1u;
@@ -1005,9 +1049,18 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         // ---- one bounce of shading for the rays whose closest hit is final ----------------------------------------------
         if (shade) {
             n_rays++;
+#if MPT_OT_HITRING
+            if (W >= 0) {
+                dest = MPT_OT_RING_R;    // the hit, as it is: shaded by the step that pops it
+            } else {                     // the sky ends the path (PathTracing.h:225-232)
+                shade_bounce(pp.scene, lds, pp.sp, g, ps, T, -1);
+                store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+            }
+#else
             if (shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W))
                 dest = MPT_OT_RING_R + (MPT_OT_NR > 1u ? (ps.d.x < 0.0f ? 1u : 0u) | (ps.d.y < 0.0f ? 2u : 0u) | (ps.d.z < 0.0f ? 4u : 0u) : 0u);
             else store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
+#endif
         }
         n_flagged += dest == MPT_OT_RING_E ? 1u : 0u;
         n_parked += dest != MPT_OT_NONE && dest >= MPT_OT_RING_M ? 1u : 0u;
@@ -1024,7 +1077,14 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             if (dest != MPT_OT_NONE) {
                 ring.od()[to] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
                 ring.dt()[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-#if MPT_WL_DIET
+#if MPT_OT_HITRING
+                {
+                    const bool lit = ring_has_light(ps);
+                    ring.ia()[to] = make_uint4(__float_as_uint(ps.thr.z), ps.path, (__float_as_uint(T) & 0x7FFFFFFFu) | (lit ? 0x80000000u : 0u),
+                                               ((uint32_t)W & 0x07FFFFFFu) | (ps.bounce << 27));
+                    if (lit) ring.tl()[to] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
+                }
+#elif MPT_WL_DIET
                 {
                     const bool lit = ring_has_light(ps);
                     ring.ia()[to] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
