@@ -12,7 +12,8 @@ else:
 sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(xml, sc); assert st == 0
 ctx = capi.Context(0); host.make_ready(ctx, sc, int(os.environ.get("BVH", "0")))   # 0 reference, 1 binned, 2 GPU through the host, 3 device build
 W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
-ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
+cam = dict(pos=(0.0, 1.0, 3.4), fwd=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), vfov=40.0) if os.environ.get("CAM") == "cornell" else None   # (bench.py's CORNELL_CAM)
+ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam))
 spp = int(os.environ.get("SPP", "16")); pipe = int(os.environ.get("PIPE", "1")); depth = int(os.environ.get("DEPTH", "8"))
 shards = int(os.environ.get("SHARDS", "1")); bsdf = int(os.environ.get("BSDF", "0"))   # SHARDS=8: rank 0's 1/8 tile shard; BSDF 1 = Scatter.h
 import json

@@ -2,12 +2,15 @@
 usage: python tools/profiles_collect.py [tag] [--pmc-only]"""
 import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
 pmc_only = "--pmc-only" in sys.argv   # (on the GPU box, between the counter passes and bench.py: the line can then name its profile)
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-notes = {"wl": ("pmc_wavelocal", "scene.xml 1920x1080, 256 spp, depth 8, device-built binned-SAH tree (leaves <= 8): the default bench.py step."),
-         "ot": ("pmc_ordered", "scene.xml 1920x1080, 256 spp, depth 8, reference tree, MPT_PIPE_ORDERED."),
-         "otb": ("pmc_ordered_bunny20", "bunny x20 (99,362 primitives, device-built binned-SAH tree) 1920x1080, 64 spp, depth 8, MPT_PIPE_ORDERED."),
+notes = {"wl": ("pmc_wavelocal", "scene.xml 1920x1080, 256 spp, depth 8, device-built binned-SAH tree (leaves <= 6): the default bench.py step."),
+         "wlref": ("pmc_wavelocal_reference_tree", "scene.xml 1920x1080, 256 spp, depth 8, the REFERENCE's own tree (Scene::buildBVH sweep SAH + mpt_upload_scene): bench.py's extra workload."),
+         "cor": ("pmc_wavelocal_cornell", "cornell.xml 1920x1080, 256 spp, depth 8, bench.py's CORNELL_CAM, device-built tree: bench.py's extra workload."),
+         "otb": ("pmc_ordered_bunny20", "bunny x20 (99,362 primitives, device-built binned-SAH tree) 1920x1080, 256 spp, depth 8, MPT_PIPE_ORDERED: bench.py's extra workload."),
+         "c4": ("pmc_ordered_config4", "configs[4]: 1,000,003 primitives (tools/config4_scene.py), device-built tree, 1920x1080, 4096 spp, depth 16, Scatter.h BSDFs, rank 0's 1/8 tile shard, MPT_PIPE_ORDERED: bench.py's extra workload."),
+         "ot": ("pmc_ordered", "scene.xml 1920x1080, 256 spp, depth 8, device-built tree, MPT_PIPE_ORDERED."),
          "wlb": ("pmc_wavelocal_bunny20", "bunny x20 (99,362 primitives, device-built binned-SAH tree) 1920x1080, 64 spp, depth 8, MPT_PIPE_WAVELOCAL.")}
 for k, (name, note) in notes.items():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_finalize.py"), tag + k, os.path.join(P, "%s_%s.json" % (tag, name)), note],
@@ -15,8 +18,8 @@ for k, (name, note) in notes.items():
 if pmc_only:
     sys.exit(0)
 mem = json.load(open(os.path.join(G, tag + "otb_mem.json")))
-mem["note"] = ("memory-pipe counters of ONE k_ordered launch on bunny x20 (64 spp; tools/pmc_mem.sh: texture addresser, vector L1, texture data, L2 requests; "
-               "one rocprofv3 --pmc pass per set).  TCP_TOTAL_CACHE_ACCESSES / TCP_TA_TCP_STATE_READ = tag look-ups per wave load instruction.")
+mem["note"] = ("memory-pipe counters of ONE k_ordered launch on bunny x20 (64 spp; tools/pmc_mem.sh: texture addresser and texture data unit at two counters a pass, vector L1 and "
+               "L2 at four; one rocprofv3 --pmc pass per set, a failed pass fails the script).  TCP_TOTAL_CACHE_ACCESSES / TCP_TA_TCP_STATE_READ = tag look-ups per wave load instruction.")
 json.dump(mem, open(os.path.join(P, tag + "_mem_ordered_bunny20.json"), "w"), indent=1)
 for f in ("bench_kernel_stats.csv", "devbuild_kernel_stats.csv", "bench_under_rocprof.json", "bench.json", "step_table.json", "step_table.txt",
           "ot_times_bunny20.json", "ot_times_bunny20.txt", "inkernel_clock.txt", "devbuild.txt", "devbuild_timeline.txt", "shard_time.txt", "depth_work.txt", "configs.txt"):
@@ -35,7 +38,7 @@ if os.path.exists(trace):
     line = [l for l in open(os.path.join(G, tag + "_bench_under_rocprof.json")) if l.startswith("{")][-1]
     b = json.loads(line)
     K, Wm = b["steps"], b["warmup"]
-    labels = ["lane set-up"] * 2 + ["warm-up"] * Wm + ["timed step"] * K + ["serial render"] * min(3, K) + ["extra: cornell.xml"] * 3 + ["extra: bunny20.xml"] * 3
+    labels = ["lane set-up"] * 2 + ["warm-up"] * Wm + ["timed step"] * K + ["serial render"] * min(3, K) + ["extra: cornell.xml"] * 3 + ["extra: bunny20.xml"] * 3 + ["extra: scene.xml on the reference's tree"] * 3 + ["extra: config4 shard"] * 3
     launches = [{"kernel": r["Kernel_Name"].split("(")[0].replace("void ", ""), "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6,
                  "what": labels[i] if i < len(labels) else "?"} for i, r in enumerate(rows)]
     timed = [x["ms"] for x in launches if x["what"] == "timed step"]
