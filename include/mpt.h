@@ -183,6 +183,10 @@ int mpt_clear_sum(mpt_ctx* ctx);
  * target of mpt_draw.  read_sum: the raw HDR sum.  Both RGBA32F, W*H*4 floats.                        */
 int mpt_read_frame(mpt_ctx* ctx, float* rgba_host);
 int mpt_read_sum(mpt_ctx* ctx, float* rgba_host);
+/* Checkpoint / resume of the accumulation (the reference keeps its running mean in a GPU-private texture and never reads it back,
+ * R/Renderer/Renderer.cpp:236, Fragment.metal:62-69): mpt_read_sum is the checkpoint, mpt_write_sum puts it back.
+ * Continuing with sample_begin = the number of samples the sum holds gives, bit for bit, the sum of an uninterrupted render.     */
+int mpt_write_sum(mpt_ctx* ctx, const float* rgba_host);
 
 int mpt_get_stats(mpt_ctx* ctx, mpt_stats* out);
 int mpt_reset_stats(mpt_ctx* ctx);

@@ -25,7 +25,7 @@ STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT
 SYMBOLS = (
     "mpt_create", "mpt_destroy", "mpt_last_error", "mpt_status_string", "mpt_upload_scene", "mpt_set_uniforms",
     "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
-    "mpt_read_frame", "mpt_read_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
+    "mpt_read_frame", "mpt_read_sum", "mpt_write_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
     "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
     "mpt_build_bvh", "mpt_build_and_upload", "mpt_download_bvh", "mpt_gpu_leaf_max", "mpt_build_info", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
     "mpt_comm_last_error",
@@ -137,6 +137,7 @@ def load():
     L.mpt_clear_sum.argtypes = [vp]
     L.mpt_read_frame.argtypes = [vp, fp]
     L.mpt_read_sum.argtypes = [vp, fp]
+    L.mpt_write_sum.argtypes = [vp, fp]
     L.mpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mpt_reset_stats.argtypes = [vp]
     L.mpt_stream.argtypes = [vp]
@@ -316,6 +317,13 @@ class Context:
         out = np.empty((self.height, self.width, 4), np.float32)
         self._chk(self.L.mpt_read_sum(self.h, _fp(out)), "mpt_read_sum")
         return out
+
+    def write_sum(self, rgba):
+        """Put an HDR sum back (checkpoint / resume): the inverse of read_sum."""
+        a = np.ascontiguousarray(rgba, np.float32)
+        if a.shape != (self.height, self.width, 4):
+            raise ValueError("write_sum: expected an array of shape (%d, %d, 4)" % (self.height, self.width))
+        self._chk(self.L.mpt_write_sum(self.h, _fp(a)), "mpt_write_sum")
 
     def stats(self):
         s = Stats()

@@ -257,6 +257,11 @@ void Renderer::readSum(std::vector<float>& rgba) {
 }
 
 void Renderer::clearSum() { check(mpt_clear_sum(ctx_), "mpt_clear_sum"); }
+void Renderer::writeSum(const std::vector<float>& rgba) {
+    const size_t n = static_cast<size_t>(Camera::screenSize.x) * static_cast<size_t>(Camera::screenSize.y) * 4;
+    if (rgba.size() != n) throw std::runtime_error("writeSum: the array does not have the size of the frame");
+    check(mpt_write_sum(ctx_, rgba.data()), "mpt_write_sum");
+}
 
 mpt_stats Renderer::stats() {
     mpt_stats s;

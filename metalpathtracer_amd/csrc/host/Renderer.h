@@ -55,6 +55,7 @@ public:
     void readFrame(OffscreenView* view);                       // running-mean target of draw()
     int renderBatch(uint32_t sampleBegin, uint32_t sampleCount); // HDR sum accumulation (mpt_render)
     void readSum(std::vector<float>& rgba);
+    void writeSum(const std::vector<float>& rgba);   // checkpoint / resume: the inverse of readSum (mpt_write_sum)
     void clearSum();
     mpt_stats stats();
 

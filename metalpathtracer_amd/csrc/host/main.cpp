@@ -24,10 +24,14 @@ static void usage() {
         "           [--pipeline auto|ordered|wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
         "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
         "           [--gpus N] [--camera-path FILE [--out-dir runs]] [--bvh reference|binned|gpu|auto]\n"
+        "           [--checkpoint FILE] [--resume FILE]\n"
         "  --bvh             tree builder: the reference's sweep SAH (default with --rng literal, --frames and --camera-path:\n"
         "                    the drop-in behaviour) or auto (default for batch renders: the tree of every scene is built on the\n"
         "                    device, mpt_build_and_upload, with leaves of <= 6 primitives below 8192 primitives and <= 2 from there\n"
         "                    on; gpu = the same); binned = the host's 16-bin SAH builder\n"
+        "  --checkpoint F    batch mode: after the render, write the HDR sum and the number of samples it holds to F\n"
+        "  --resume F        batch mode: start from the checkpoint F (same scene, size, seed and RNG) and add --spp MORE samples, numbered\n"
+        "                    from where it stopped: the result is bit-identical to one uninterrupted render of all the samples\n"
         "  --frames N        run the reference's frame protocol (N draw() calls, running mean) instead of batch spp\n"
         "  --gpus N          batch mode on GPUs device .. device+N-1: 8x8 pixel tiles interleaved over the GPUs, one RCCL\n"
         "                    reduce(sum) of the HDR framebuffer onto the first (mpt_comm_create_all / mpt_reduce_sum)\n"
@@ -188,7 +192,7 @@ static int renderOnSeveralGpus(const std::string& scene, const std::string& asse
 }
 
 int main(int argc, char** argv) {
-    std::string scene, assetRoot, out, cameraPath, outDir = "runs";
+    std::string scene, assetRoot, out, cameraPath, outDir = "runs", checkpoint, resume;
     int width = 1280, height = 720, spp = 64, depth = 32, device = 0, frames = 0, gpus = 1;
     int bvh = -1;   // -1 = by mode: the reference's builder for the frame protocol / the literal RNG, auto for batch renders
     unsigned seed = 1;
@@ -221,6 +225,8 @@ int main(int argc, char** argv) {
         else if (a == "--camera-path") cameraPath = next();
         else if (a == "--out-dir") outDir = next();
         else if (a == "--out") out = next();
+        else if (a == "--checkpoint") checkpoint = next();
+        else if (a == "--resume") resume = next();
         else if (a == "--bvh") {
             const char* v = next();
             bvh = std::strcmp(v, "reference") == 0 ? Renderer::BUILD_REFERENCE
@@ -288,10 +294,38 @@ int main(int argc, char** argv) {
             r.readFrame(&view);
             img = view.rgba;
         } else {
+            // checkpoint / resume of the accumulation (the reference's running mean lives in a GPU-private texture and is lost with the
+            // process, R/Renderer/Renderer.cpp:236): header "MPTSUM1 W H samples seed rng depth\n" + W * H * 4 raw floats
+            uint32_t have = 0;
             r.clearSum();
-            r.renderBatch(0, static_cast<uint32_t>(spp));
+            if (!resume.empty()) {
+                FILE* f = std::fopen(resume.c_str(), "rb");
+                int w = 0, h = 0, rngm = 0, dep = 0;
+                unsigned sd = 0;
+                if (!f || std::fscanf(f, "MPTSUM1 %d %d %u %u %d %d", &w, &h, &have, &sd, &rngm, &dep) != 6 || std::fgetc(f) != '\n') {
+                    if (f) std::fclose(f);
+                    throw std::runtime_error("cannot read the checkpoint " + resume);
+                }
+                if (w != width || h != height || sd != seed || rngm != prm.rng_mode || dep != depth) {
+                    std::fclose(f);
+                    throw std::runtime_error("the checkpoint " + resume + " was written with another size, seed, RNG or depth");
+                }
+                std::vector<float> sum(static_cast<size_t>(w) * h * 4);
+                const size_t got = std::fread(sum.data(), sizeof(float), sum.size(), f);
+                std::fclose(f);
+                if (got != sum.size()) throw std::runtime_error("the checkpoint " + resume + " is truncated");
+                r.writeSum(sum);
+            }
+            r.renderBatch(have, static_cast<uint32_t>(spp));
             r.readSum(img);
-            scale = 1.0f / static_cast<float>(spp);
+            if (!checkpoint.empty()) {
+                FILE* f = std::fopen(checkpoint.c_str(), "wb");
+                if (!f) throw std::runtime_error("cannot write " + checkpoint);
+                std::fprintf(f, "MPTSUM1 %d %d %u %u %d %d\n", width, height, have + static_cast<uint32_t>(spp), seed, prm.rng_mode, depth);
+                const bool ok = std::fwrite(img.data(), sizeof(float), img.size(), f) == img.size();
+                if (std::fclose(f) != 0 || !ok) throw std::runtime_error("cannot write " + checkpoint);
+            }
+            scale = 1.0f / static_cast<float>(have + static_cast<uint32_t>(spp));
         }
         double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         mpt_stats st = r.stats();

@@ -1083,6 +1083,13 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     pp.sample_begin = sample_begin;
     pp.rank = rk;
     pp.nranks = nr;
+    {   // path -> pixel by arithmetic when the tiles are walked in row-major order: T / tiles_x = umulhi(T, ceil(2^32 / tiles_x)) is exact
+        // while T * tiles_x < 2^32 (error term T * (tiles_x - 1) / (tiles_x * 2^32) < 1 / tiles_x); otherwise the table
+        const uint64_t tiles = (uint64_t)tiles_x * ((ctx->H + 7) / 8);
+        pp.tile_magic = 0u;
+        if (ctx->tile_order_mode == 0 && tiles_x >= 2u && tiles * tiles_x < (1ull << 32) && getenv("MPT_TILE_TABLE") == nullptr)
+            pp.tile_magic = (uint32_t)(((1ull << 32) + tiles_x - 1u) / tiles_x);
+    }
     pp.sp.rng_mode = p->rng_mode;
     pp.sp.bsdf_mode = p->bsdf_mode;
     pp.sp.max_depth = p->max_depth;
@@ -1696,6 +1703,23 @@ extern "C" int mpt_read_frame(mpt_ctx* ctx, float* out) {
 
 extern "C" int mpt_read_sum(mpt_ctx* ctx, float* out) {
     return guarded(ctx, [&] { return read_sum_impl(ctx, out); });
+}
+
+// The inverse: the HDR sum of an earlier run goes back in (checkpoint / resume of the accumulation: with the sample index the
+// caller continues from, the resumed render is bit-identical to an uninterrupted one — sum[p] += sample_s in sample order either way).
+static int write_sum_impl(mpt_ctx* ctx, const float* in) {
+    if (!ctx || !in) return MPT_ERR_INVALID_ARG;
+    if (!ctx->d_sum) return fail(ctx, MPT_ERR_NOT_READY, "mpt_resize not called");
+    int wrc = wait_impl(ctx);
+    if (wrc) return wrc;
+    HIPCHK(hipMemcpyAsync(ctx->d_sum, in, (size_t)ctx->W * ctx->H * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev_sum_op, ctx->stream));   // the next resolve (on either lane) is ordered behind the upload
+    ctx->last_resolved = ctx->ev_sum_op;
+    HIPCHK(hipStreamSynchronize(ctx->stream));             // (the host array may be freed on return)
+    return MPT_OK;
+}
+extern "C" int mpt_write_sum(mpt_ctx* ctx, const float* rgba_host) {
+    return guarded(ctx, [&] { return write_sum_impl(ctx, rgba_host); });
 }
 
 extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {

@@ -68,6 +68,8 @@ struct PassParams {
     uint32_t s_shift;            // log2(S) when S is a power of two, else 0xFF
     const uint32_t* tile_xy;     // this rank's tiles in processing order: x | y << 16
     uint32_t rank, nranks;
+    uint32_t tile_magic;         // != 0: the rank's k-th tile is tile T = k * nranks + rank in row-major order (tile order 0) and
+                                 // T / tiles_x = umulhi(T, tile_magic) exactly (the host checks the range): path -> pixel needs no table load
     ShadeParams sp;
     volatile uint32_t* host_done;
 };
@@ -129,9 +131,15 @@ __device__ __forceinline__ bool path_to_pixel(const PassParams& pp, uint32_t pat
         tl = chunk / pp.S;
         s = chunk - tl * pp.S;
     }
-    const uint32_t xy = pp.tile_xy[tl];
-    px = (xy & 0xFFFFu) * 8u + (lane & 7u);
-    py = (xy >> 16) * 8u + (lane >> 3);
+    if (pp.tile_magic != 0u) {   // (wave-uniform) arithmetic instead of a dependent table load: the hit rings recompute the pixel of every popped record
+        const uint32_t T = tl * pp.nranks + pp.rank, ty = __umulhi(T, pp.tile_magic), tx = T - ty * pp.tiles_x;
+        px = tx * 8u + (lane & 7u);
+        py = ty * 8u + (lane >> 3);
+    } else {
+        const uint32_t xy = pp.tile_xy[tl];
+        px = (xy & 0xFFFFu) * 8u + (lane & 7u);
+        py = (xy >> 16) * 8u + (lane >> 3);
+    }
     return px < pp.width && py < pp.height;
 }
 

@@ -886,10 +886,9 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             }
             if (kind >= MPT_OT_RING_M) {  // a parked walk brings its stack along: back into this lane's LDS column
                 if (!valid) walk_cur = MPT_OT_DONE;
-                const uint32_t deepest = wave_max_u32(valid ? walk_sp : 0u);
 #pragma unroll
                 for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
-                    if (2u * k >= deepest) break;
+                    if (__ballot(valid && walk_sp > 2u * k) == 0ull) break;   // (no lane's stack is this deep: one ballot, not a maximum over the lanes by six ds_bpermute)
                     if (valid && walk_sp > 2u * k) {
                         const uint4 e = ot_pop4u(ring.sk(k) + at);
                         st.lds[(2u * k) * 64u] = v2u{e.x, e.y};

@@ -598,3 +598,42 @@ def test_headline_config_is_bit_identical_to_the_oracle(pipe, bvh):
     if "CROSS" in env:
         assert "cross-tree L2 < 1e-3: True" in r.stdout
     print(r.stdout)
+
+
+def test_checkpoint_and_resume_of_the_accumulation(gpu_ctx, tmp_path):
+    """SURVEY.md 5 "checkpoint / resume" (the reference keeps its running mean in a GPU-private texture and loses it with the
+    process): mpt_read_sum is the checkpoint, mpt_write_sum puts it back — through the C ABI and through the CLI
+    (`mpt_render --checkpoint F`, `--resume F`): 5 samples, checkpoint, a fresh context, 3 more samples numbered from where the
+    first run stopped == 8 samples in one go, every float."""
+    import os, subprocess
+    from conftest import ROOT
+    from metalpathtracer_amd import capi
+    W, H = 160, 90
+    buf, uo = setup(gpu_ctx, "scene.xml", W, H)
+    kw = dict(rng_mode=capi.RNG_PHILOX, max_depth=8, seed=(7, 1))
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(sample_begin=0, sample_count=8, **kw)
+    whole = gpu_ctx.read_sum()
+    gpu_ctx.clear_sum()
+    gpu_ctx.render(sample_begin=0, sample_count=5, **kw)
+    ckpt = gpu_ctx.read_sum()
+    other = capi.Context(0)                                   # "another process": nothing survives but the checkpoint
+    try:
+        other.upload_scene(*buf)
+        other.resize(W, H)
+        other.set_uniforms(capi.Uniforms.from_buffer_copy(bytes(uo)))
+        other.write_sum(ckpt)
+        other.render(sample_begin=5, sample_count=3, **kw)
+        np.testing.assert_array_equal(other.read_sum().view(np.uint32), whole.view(np.uint32))
+    finally:
+        other.close()
+    exe = os.path.join(ROOT, "metalpathtracer_amd", "lib", "mpt_render")
+    base = [exe, "--scene", scene_path("scene.xml"), "--width", "96", "--height", "54", "--depth", "8", "--seed", "3"]
+    a, b, c = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm"), str(tmp_path / "c.bin")
+    for args in (["--spp", "8", "--out", a], ["--spp", "5", "--checkpoint", c], ["--spp", "3", "--resume", c, "--out", b]):
+        r = subprocess.run(base + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    assert open(c, "rb").read(8) == b"MPTSUM1 " and os.path.getsize(c) > 96 * 54 * 16
+    assert open(a, "rb").read() == open(b, "rb").read()       # the resumed image file is the uninterrupted one, byte for byte
+    r = subprocess.run(base + ["--spp", "3", "--resume", c, "--seed", "4"], capture_output=True, text=True)
+    assert r.returncode != 0 and "another size, seed" in r.stderr    # a checkpoint of another run is refused
