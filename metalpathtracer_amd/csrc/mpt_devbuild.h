@@ -385,6 +385,16 @@ __global__ void k_collapse_emit(CollapseAcc A, int n, const int2* range, const u
     for (uint32_t q = 0; q < MPT_OT_NODE_STRIDE; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
 
+// refbox[2 i], [2 i + 1] = the box of primitive i's reference leaf, what ot_final_check (mpt_ordered.h) tests the winner against:
+// indexed by the primitive, so that the check is ONE memory round trip (not the primitive record first and the leaf's box after it)
+__global__ void k_prim_refbox(const float4* dprims, const float4* refleaf, uint32_t n_prims, float4* refbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_prims) return;
+    const uint32_t leaf = prim_ref_leaf(dprims[3 * (size_t)i]);
+    refbox[2 * (size_t)i] = refleaf[2 * (size_t)leaf];
+    refbox[2 * (size_t)i + 1] = refleaf[2 * (size_t)leaf + 1];
+}
+
 // ---- the always list (<= 16 spheres): 5 float4 each, in the order of the device primitive array ---------------------------------
 __global__ void k_always(Scalars* sc, float4* dprims, const float4* refleaf, float4* always) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -416,13 +426,13 @@ __global__ void k_always(Scalars* sc, float4* dprims, const float4* refleaf, flo
 // (d_prims_in: 3 float4 per primitive, d_mats_in: 2 float4 per primitive).  All outputs are hipMalloc'ed here and handed to
 // the caller (who frees them); scratch is freed on return.
 struct Built {
-    float4 *nodes = nullptr, *prims = nullptr, *mats = nullptr, *acc_nodes = nullptr, *refleaf = nullptr, *always = nullptr;
+    float4 *nodes = nullptr, *prims = nullptr, *mats = nullptr, *acc_nodes = nullptr, *refleaf = nullptr, *refbox = nullptr, *always = nullptr;
     float4* ref_bvh = nullptr;   // the same tree in the reference's buffer format (2 float4 per node) ...
     int* ref_idx = nullptr;      // ... and its primitiveIndices
     uint32_t n_nodes = 0, n_prims = 0, n_mats = 0, n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, n_spheres = 0;
     float tri_extent = 0.0f;
     void release() {
-        hipFree(nodes); hipFree(prims); hipFree(mats); hipFree(acc_nodes); hipFree(refleaf); hipFree(always); hipFree(ref_bvh); hipFree(ref_idx);
+        hipFree(nodes); hipFree(prims); hipFree(mats); hipFree(acc_nodes); hipFree(refleaf); hipFree(refbox); hipFree(always); hipFree(ref_bvh); hipFree(ref_idx);
         *this = Built{};
     }
 };
@@ -632,6 +642,9 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     }
     MPT_LB(hipMalloc(&out.always, (size_t)MPT_ACCEL_MAX_ALWAYS * 80));
     hipLaunchKernelGGL(k_always, dim3(1), dim3(64), 0, stream, d_sc, out.prims, (const float4*)out.refleaf, out.always);
+    MPT_LB(hipGetLastError());
+    MPT_LB(hipMalloc(&out.refbox, (size_t)n * 32));
+    hipLaunchKernelGGL(k_prim_refbox, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const float4*)out.prims, (const float4*)out.refleaf, n, out.refbox);
     MPT_LB(hipGetLastError());
     Scalars h;
     MPT_LB(hipMemcpyAsync(&h, d_sc, sizeof h, hipMemcpyDeviceToHost, stream));

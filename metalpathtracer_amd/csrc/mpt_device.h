@@ -218,10 +218,18 @@ __device__ __forceinline__ Prim3 load_prim(const SceneDev& sc, LdsNodes lds, uin
 template <bool COUNT>
 __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint32_t first, uint32_t count, F3 o, F3 d,
                                           float& best_t, int& best_prim, WorkCount& wc) {
+#ifdef MPT_WL_PREFETCH   // (experiment) primitive k + 1 is loaded while k is tested
+    Prim3 nxt = load_prim(sc, lds, first);
+#endif
     for (uint32_t k = 0; k < count; ++k) {
         // the three 16-byte loads of a primitive are issued together (the third is used by triangles only, but a
         // load that waits for the type check costs a second L2 round trip per primitive)
+#ifdef MPT_WL_PREFETCH
+        const Prim3 pr = nxt;
+        if (k + 1u < count) nxt = load_prim(sc, lds, first + k + 1u);
+#else
         const Prim3 pr = load_prim(sc, lds, first + k);
+#endif
         const float4 p0 = pr.p0, p1 = pr.p1, p2 = pr.p2;
         if (COUNT) {
             wc.prim_tests++;

@@ -106,6 +106,7 @@ struct mpt_ctx {
     float4* d_acc_qnodes = nullptr;   // the same nodes in the 64-byte form the walk fetches from global memory (mpt_ordered.h)
     uint32_t n_acc_float = 0;         // ... of which so many could not be quantised and are fetched as floats (degenerate boxes)
     float4* d_refleaf = nullptr;
+    float4* d_refbox = nullptr;       // the box of its reference leaf PER PRIMITIVE, 2 float4 each: the final check of the closest-first walk needs no look-up through the primitive
     float4* d_always = nullptr;
     uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, ot_lds_nodes = 0, ot_lds_prims = 0;
     // mpt_build_and_upload keeps its tree in the reference's buffer format on the device too (mpt_download_bvh)
@@ -337,6 +338,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_mats);
     hipFree(ctx->d_acc_nodes);
     hipFree(ctx->d_acc_qnodes);
+    hipFree(ctx->d_refbox);
     hipFree(ctx->d_refleaf);
     hipFree(ctx->d_always);
     hipFree(ctx->d_ref_bvh);
@@ -417,6 +419,18 @@ static void size_lds_images(mpt_ctx* ctx) {
 
 // The 64-byte form of the own tree's nodes (k_quantize_nodes, mpt_ordered.h): derived on the device from the float nodes, whichever
 // route made them.
+// the per-primitive reference-leaf boxes of an uploaded scene (k_prim_refbox, mpt_devbuild.h)
+static int make_prim_refbox(mpt_ctx* ctx) {
+    hipFree(ctx->d_refbox);
+    ctx->d_refbox = nullptr;
+    if (ctx->n_prims == 0 || ctx->d_refleaf == nullptr || ctx->n_ref_leaves == 0) return MPT_OK;
+    HIPCHK(hipMalloc(&ctx->d_refbox, (size_t)ctx->n_prims * 32));
+    hipLaunchKernelGGL(mpt_devbuild::k_prim_refbox, dim3((ctx->n_prims + 255u) / 256u), dim3(256), 0, ctx->stream, (const float4*)ctx->d_prims,
+                       (const float4*)ctx->d_refleaf, ctx->n_prims, ctx->d_refbox);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MPT_OK;
+}
 static int quantize_acc_nodes(mpt_ctx* ctx) {
     hipFree(ctx->d_acc_qnodes);
     ctx->d_acc_qnodes = nullptr;
@@ -770,6 +784,10 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     }
     ctx->n_always = (uint32_t)(always.size() / 20);
     ctx->n_ref_leaves = (uint32_t)(refleaf.size() / 8);
+    {
+        int rrc = make_prim_refbox(ctx);
+        if (rrc) return rrc;
+    }
     ctx->acc_depth = topo.depth;
     ctx->tri_extent = tri_extent;
     ctx->acc_eps_abs = tri_extent * 3.814697265625e-06f;  // 2^-18 of the largest triangle coordinate
@@ -901,6 +919,7 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     a.nodes = ctx->d_acc_nodes;
     a.qnodes = ctx->d_acc_qnodes;
     a.refleaf = ctx->d_refleaf;
+    a.refbox = ctx->d_refbox;
     a.always = ctx->d_always;
     a.n_nodes = ctx->n_acc_nodes;
     a.n_lds_nodes = ctx->ot_lds_nodes;
@@ -1626,6 +1645,8 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
         if (qrc) return qrc;
     }
     ctx->d_refleaf = b.refleaf;
+    hipFree(ctx->d_refbox);
+    ctx->d_refbox = b.refbox;
     ctx->d_always = b.always;
     ctx->d_ref_bvh = b.ref_bvh;
     ctx->d_ref_idx = b.ref_idx;

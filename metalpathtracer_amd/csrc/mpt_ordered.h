@@ -73,6 +73,12 @@
 // hit pushes the hit (ray, t, primitive) to ring R instead of shading it at whatever width the step happens to have — the always-list
 // sphere hits of a top test, the finished walks of a ring-M step, the re-traced rays of ring E — and the step that pops 64 hits
 // shades them all at full width, then runs the top test on the 64 bounce rays.  Same number of ring hops, same record size.
+#ifndef MPT_OT_REFBOX
+#define MPT_OT_REFBOX 1   // 1: the final check reads the reference leaf's box by primitive index (one round trip); 0: through the primitive record (two)
+#endif
+#ifndef MPT_OT_LEAF2
+#define MPT_OT_LEAF2 1   // 1: the first two primitives of a leaf are loaded together
+#endif
 #ifndef MPT_OT_HITRING
 #define MPT_OT_HITRING 1
 #endif
@@ -152,6 +158,7 @@ struct AccelDev {
     const float4* nodes;    // MPT_OT_NODE_STRIDE float4 per node (7 used), breadth-first (mpt_accel.h)
     const float4* qnodes;   // the same nodes, 4 float4 each (quantised child boxes)
     const float4* refleaf;  // 2 float4 per reference leaf: (bmin, 0) (bmax, 0)
+    const float4* refbox;   // the same boxes per PRIMITIVE (2 float4 each; k_prim_refbox, mpt_devbuild.h): what the final check reads
     const float4* always;   // 5 float4 per sphere of the always list: (c, leaf<<1) (r, bits(index), bits(k), mat) (0,0,0, orig id)
                             // + the box of its reference leaf (bmin, 0) (bmax, 0)
     uint32_t n_nodes, n_lds_nodes, n_always;
@@ -416,6 +423,9 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                                         const OtRay& r, uint32_t& cur, uint32_t& sp, float& T, int& W, bool& tie,
                                         bool& overflow, uint32_t budget, uint32_t min_active, WorkCount& wc) {
     uint32_t trips = 0;
+#ifdef MPT_OT_TOUCH
+    float touch = 0.0f;
+#endif
 #ifdef MPT_OT_TIMES
     unsigned long long wt_ = __builtin_amdgcn_s_memtime();
 #define OT_WTOC(field)                                                \
@@ -471,15 +481,48 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             } else {
                 cur = ot_pop_next(st, sp, lim);
             }
+#ifdef MPT_OT_TOUCH   // (experiment) a lane that has just found its leaf touches the leaf's first primitive: the line is on its way while the others search
+            if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF && (cur & 0x07FFFFFFu) >= sc.n_lds_prims) touch = sc.prims[3u * (size_t)(cur & 0x07FFFFFFu)].x;
+#endif
         }
         OT_WTOC(ot_node_cycles);
         if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF) {  // a leaf: primitives [first, first + count) in index order
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
             if (COUNT && first_active_lane()) wc.outer_iters++;
+#if MPT_OT_LEAF2
+            // The first two primitives of the leaf are loaded TOGETHER (one memory round trip, not two: the walk is a chain of
+            // latencies, and the big scenes' leaves hold at most two), then tested in index order as before.
+            uint32_t k_from = 0u;
+            {
+                const bool two = count > 1u;
+                const Prim3 pa = load_prim(sc, lds, first);
+                Prim3 pb = pa;
+                if (two) pb = load_prim(sc, lds, first + 1u);
+#ifdef MPT_OT_TIMES
+                if (first_active_lane()) wc.ot_leaf_trips++;
+                wc.ot_leaf_lanes++;
+#endif
+                if (COUNT && first_active_lane()) wc.prim_iters++;
+                if (!(ac.n_always != 0u && prim_type(pa.p0) == 0)) {
+                    if (COUNT) wc.prim_tests++;
+                    ot_test_prim(pa, first, o, d, T, W, tie);
+                }
+                if (two) {
+                    if (COUNT && first_active_lane()) wc.prim_iters++;
+                    if (!(ac.n_always != 0u && prim_type(pb.p0) == 0)) {
+                        if (COUNT) wc.prim_tests++;
+                        ot_test_prim(pb, first + 1u, o, d, T, W, tie);
+                    }
+                }
+                k_from = 2u;
+            }
+            for (uint32_t k = k_from; k < count; ++k) {
+#else
 #ifdef MPT_OT_PREFETCH   // loading primitive k + 1 while k is tested: measured slower (12 more VGPRs live: 28.7 vs 28.1 ms)
             Prim3 nxt = load_prim(sc, lds, first);
 #endif
             for (uint32_t k = 0; k < count; ++k) {
+#endif
 #ifdef MPT_OT_PREFETCH
                 const Prim3 pr = nxt;
                 if (k + 1u < count) nxt = load_prim(sc, lds, first + k + 1u);
@@ -500,6 +543,9 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             cur = ot_pop_next(st, sp, ot_cull_limit(T, ac));
         }
         OT_WTOC(ot_leaf_cycles);
+#ifdef MPT_OT_TOUCH
+        asm volatile("" ::"v"(touch));
+#endif
         const unsigned long long going = __ballot(cur != MPT_OT_DONE && (!BUDGETED || trips < budget));
         if (going == 0ull) break;
         if (BUDGETED && (uint32_t)__popcll(going) < min_active) break;
@@ -514,6 +560,12 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
 // skipped — they are needed only for winners within that bound of their box (hits on the ground sphere next to the origin).
 __device__ __forceinline__ bool ot_final_check(const AccelDev& ac, const SceneDev& sc, LdsNodes lds, F3 o, F3 d, const OtRay& r,
                                                float T, int W) {
+#if MPT_OT_REFBOX
+    // the box of the winner's reference leaf, by primitive: two loads, one round trip (sc, lds: not needed)
+    const float4 n0 = ac.refbox[2u * (size_t)(uint32_t)W], n1 = ac.refbox[2u * (size_t)(uint32_t)W + 1u];
+    (void)sc;
+    (void)lds;
+#else
     const Prim3 pr = load_prim(sc, lds, (uint32_t)W);
     float4 n0, n1;
     if (ac.n_always != 0u && prim_type(pr.p0) == 0) {  // a sphere of the always list: its leaf box is in LDS
@@ -526,6 +578,7 @@ __device__ __forceinline__ bool ot_final_check(const AccelDev& ac, const SceneDe
         n0 = ac.refleaf[2u * (size_t)leaf];
         n1 = ac.refleaf[2u * (size_t)leaf + 1u];
     }
+#endif
     {
         float t0 = fmaf(n0.x, r.idx, -r.ox), t1 = fmaf(n1.x, r.idx, -r.ox);
         float lo = fminf(t0, t1), hi = fmaxf(t0, t1), m = fmaxf(fabsf(t0), fabsf(t1));
