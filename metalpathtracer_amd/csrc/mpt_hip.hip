@@ -74,7 +74,7 @@ struct Lane {
     uint32_t* d_ctr = nullptr;
     uint32_t* h_done = nullptr;  // pinned, device-visible
     PassDesc* h_desc = nullptr;  // pinned copy of the pass descriptor (statistics read-back without a sync copy)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_resolved = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_resolved = nullptr, ev_traced = nullptr;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_timed;  // kernel-event pairs to read at collection
@@ -92,6 +92,10 @@ struct mpt_ctx {
     Lane lane[2];
     int next_lane = 0;
     hipEvent_t last_resolved = nullptr;  // last operation on the HDR sum (resolve or clear): the next resolve waits for it
+    hipEvent_t last_traced = nullptr;    // behind the last trace kernel enqueued (either lane): the next trace kernel waits for it (lane_order)
+    int resolve_wgs_per_cu = 2;          // MPT_RESOLVE_WGS: workgroups of 256 per CU of a resolve that runs beside a trace kernel (0 = as many as pixels / 256)
+    bool sync_render = false;            // inside mpt_render / mpt_draw: nothing else is in flight, the resolve may take the whole chip
+    int lane_order = 1;                  // MPT_LANE_ORDER: bit 0 = trace kernels run one after the other, bit 1 = lane 0's stream has the higher priority
     hipEvent_t ev_sum_op = nullptr;      // recorded behind mpt_clear_sum
     hipDeviceProp_t prop;
     std::string err;
@@ -221,8 +225,14 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
     };
     if (hipSetDevice(device_ordinal) != hipSuccess) return bail(MPT_ERR_HIP);
     if (hipGetDeviceProperties(&ctx->prop, device_ordinal) != hipSuccess) return bail(MPT_ERR_HIP);
+    if (const char* lo = getenv("MPT_LANE_ORDER")) ctx->lane_order = atoi(lo);
+    if (const char* rw = getenv("MPT_RESOLVE_WGS")) ctx->resolve_wgs_per_cu = std::max(0, atoi(rw));
+    int prio_lo = 0, prio_hi = 0;   // (numerically lower = higher priority)
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
     for (Lane& L : ctx->lane) {  // small per-lane state now; slots, rings and queues are allocated on first use
-        if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) return bail(MPT_ERR_HIP);
+        if (ctx->lane_order & 2) {
+            if (hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, &L == &ctx->lane[0] ? prio_hi : prio_lo) != hipSuccess) return bail(MPT_ERR_HIP);
+        } else if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) return bail(MPT_ERR_HIP);
         if (hipMalloc(&L.d_desc, sizeof(PassDesc)) != hipSuccess) return bail(MPT_ERR_HIP);
         if (hipMemset(L.d_desc, 0, sizeof(PassDesc)) != hipSuccess) return bail(MPT_ERR_HIP);
         if (hipMalloc(&L.d_ctr, MPT_CTR_WORDS * 4) != hipSuccess) return bail(MPT_ERR_HIP);
@@ -231,7 +241,7 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
         if (hipHostMalloc((void**)&L.h_desc, sizeof(PassDesc), hipHostMallocDefault) != hipSuccess) return bail(MPT_ERR_HIP);
         *L.h_done = 0;
         if (hipEventCreate(&L.ev0) != hipSuccess || hipEventCreate(&L.ev1) != hipSuccess ||
-            hipEventCreate(&L.ev_resolved) != hipSuccess)
+            hipEventCreate(&L.ev_resolved) != hipSuccess || hipEventCreateWithFlags(&L.ev_traced, hipEventDisableTiming) != hipSuccess)
             return bail(MPT_ERR_HIP);
     }
     ctx->stream = ctx->lane[0].stream;
@@ -360,6 +370,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
         if (L.ev0) hipEventDestroy(L.ev0);
         if (L.ev1) hipEventDestroy(L.ev1);
         if (L.ev_resolved) hipEventDestroy(L.ev_resolved);
+        if (L.ev_traced) hipEventDestroy(L.ev_traced);
         for (auto e : L.ev_pool) hipEventDestroy(e);
         if (L.stream) hipStreamDestroy(L.stream);
     }
@@ -1149,6 +1160,11 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     const int grid = ctx->prop.multiProcessorCount * per_cu;
     hipStream_t st = L.stream;
     *L.h_done = 0;
+    // Trace kernels are persistent and sized for the whole chip: two of them must never be dispatched side by side (each would hold
+    // half of the workgroup slots for its whole life — measured: 21.7 ms per 256-spp step instead of 16.8), and which of two pending
+    // launches the hardware starts is not ours to choose.  So a trace kernel waits for the one enqueued before it, on whichever lane;
+    // what the second lane overlaps with it is everything else: the resolve of the render before, the statistics copy, the host.
+    if ((ctx->lane_order & 1) && ctx->last_traced && ctx->last_traced != L.ev_traced) HIPCHK(hipStreamWaitEvent(st, ctx->last_traced, 0));
     hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, L.d_desc, L.d_ctr, (uint32_t)pass_paths, slots_items,
                        (volatile uint32_t*)dev_done, pipeline == MPT_PIPE_WAVEFRONT ? 0 : 1);
     if (pipeline != MPT_PIPE_WAVEFRONT) {
@@ -1201,6 +1217,10 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
         if (time_kernels) {
             HIPCHK(hipEventRecord(e1, st));
             L.pending_timed.emplace_back(e0, e1);
+        }
+        if (ctx->lane_order & 1) {
+            HIPCHK(hipEventRecord(L.ev_traced, st));
+            ctx->last_traced = L.ev_traced;
         }
         ctx->stats.iterations += 1;
         return MPT_OK;
@@ -1388,8 +1408,11 @@ static int render_async_impl(mpt_ctx* ctx, const mpt_render_params* p) {
             // sum[p] += pass total must happen in submission order on both lanes (float addition does not commute
             // bit for bit): this resolve waits for the previous one, wherever it ran
             if (ctx->last_resolved) HIPCHK_AB(hipStreamWaitEvent(L.stream, ctx->last_resolved, 0));
-            uint32_t threads = nlt * 64u;
-            hipLaunchKernelGGL(k_resolve_sum, dim3((threads + 255) / 256), dim3(256), 0, L.stream, pp, ctx->d_sum, nlt);
+            // beside the other lane's trace kernel: a footprint that fits next to it on every CU (k_resolve_sum); alone: the whole chip
+            const uint32_t threads = nlt * 64u, wide = (threads + 255u) / 256u;
+            const uint32_t narrow = (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)ctx->resolve_wgs_per_cu;
+            const uint32_t rgrid = !ctx->sync_render && ctx->resolve_wgs_per_cu > 0 ? std::min(wide, narrow) : wide;
+            hipLaunchKernelGGL(k_resolve_sum, dim3(rgrid), dim3(256), 0, L.stream, pp, ctx->d_sum, nlt);
             HIPCHK_AB(hipGetLastError());
             HIPCHK_AB(hipEventRecord(L.ev_resolved, L.stream));
             ctx->last_resolved = L.ev_resolved;
@@ -1412,7 +1435,10 @@ static int render_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     ctx->stats.trace_launches = 0;
     ctx->stats.total_ms = 0;
     ctx->next_lane = 0;  // nothing is in flight: serial renders stay on lane 0 (the second lane allocates only if used)
-    if ((rc = render_async_impl(ctx, p))) return rc;
+    ctx->sync_render = true;
+    rc = render_async_impl(ctx, p);
+    ctx->sync_render = false;
+    if (rc) return rc;
     return wait_impl(ctx);
 }
 

@@ -995,22 +995,34 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
 }
 
-// sum[pixel] += sum over the pass's samples (in sample order) of the clamped per-sample colour
-__global__ void k_resolve_sum(PassParams pp, float4* sum, uint32_t n_local_tiles) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_local_tiles * 64u) return;
-    uint32_t tl = i >> 6, lane = i & 63u;
-    uint32_t px, py, s0;
-    if (!path_to_pixel(pp, (tl * pp.S) * 64u + lane, px, py, s0)) return;
-    float4 acc = sum[py * pp.width + px];
-    for (uint32_t s = 0; s < pp.S; ++s) {
-        float4 v = load_slot(pp.slots, (tl * pp.S + s) * 64u + lane);
-        acc.x += v.x;
-        acc.y += v.y;
-        acc.z += v.z;
-        acc.w += v.w;
+// sum[pixel] += sum over the pass's samples (in sample order) of the clamped per-sample colour.
+// Grid-stride: the host chooses the footprint.  A resolve that runs BESIDE the next render's trace kernel gets two workgroups of 256 per
+// CU — 2 waves per SIMD next to the trace kernel's 6 and inside the VGPRs it leaves (launch bound 256 x 8: <= 64), so that both fit on every
+// CU whichever is dispatched first; a resolve with the chip to itself gets a workgroup per 256 pixels.  Four loads in flight per thread;
+// the additions stay in sample order.
+__global__ __launch_bounds__(256, 8) void k_resolve_sum(PassParams pp, float4* sum, uint32_t n_local_tiles) {
+    const uint32_t n = n_local_tiles * 64u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t tl = i >> 6, lane = i & 63u;
+        uint32_t px, py, s0;
+        if (!path_to_pixel(pp, (tl * pp.S) * 64u + lane, px, py, s0)) continue;
+        float4 acc = sum[py * pp.width + px];
+        const uint32_t base = tl * pp.S;
+        uint32_t s = 0;
+        for (; s + 4u <= pp.S; s += 4u) {
+            const float4 v0 = load_slot(pp.slots, (base + s) * 64u + lane), v1 = load_slot(pp.slots, (base + s + 1u) * 64u + lane),
+                         v2 = load_slot(pp.slots, (base + s + 2u) * 64u + lane), v3 = load_slot(pp.slots, (base + s + 3u) * 64u + lane);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; s < pp.S; ++s) {
+            const float4 v = load_slot(pp.slots, (base + s) * 64u + lane);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        sum[py * pp.width + px] = acc;
     }
-    sum[py * pp.width + px] = acc;
 }
 
 // Fragment.metal:23-27,62-69 — running mean with the frameCount+1 weight and the clamp.
