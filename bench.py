@@ -81,6 +81,8 @@ def counter_profile(kernel, workload):
             continue
         if any(wl.get(k) != workload[k] for k in ("scene", "width", "height", "spp", "depth", "bvh", "env")):
             continue
+        if wl.get("launch", "sync") != workload.get("launch", "sync"):   # mpt_render_async runs another variant of k_wavelocal than mpt_render
+            continue
         rel = os.path.relpath(f, ROOT)
         if wl.get("source_sha256") != bid["source_sha256"] and wl.get("lib_sha256") != bid["lib_sha256"]:
             stale = stale or {"profile_stale": True, "profile": rel, "profile_source_sha256": wl.get("source_sha256"),
@@ -394,12 +396,13 @@ def main():
             rays_per_launch = rays_local / launches
             sec_per_launch = kernel_ms * 1e-3 / launches
             workload = {"scene": os.path.basename(args.scene), "width": W, "height": H, "spp": spp, "depth": args.depth,
-                        "bvh": BVH_CODE[args.bvh], "env": capi.knob_env()}
+                        "bvh": BVH_CODE[args.bvh], "env": capi.knob_env(), "launch": "async"}   # (the timed steps are mpt_render_async)
             rf = {"kernel": PIPE_KERNEL[pipe], "launches": launches, "avg_launch_ms": kernel_ms / launches,
                   "rays_per_launch": rays_per_launch}
             # THE fraction: this rank's rays of the timed region over the WALL time of the timed region (the same clock `value` is
-            # quoted on) — what the chip delivered.  The K launches of the region overlap in pairs on the two render lanes, so the
-            # HIP-event duration of a single launch is longer than ms_per_step; fractions per launch are kept under `per_launch`.
+            # quoted on) — what the chip delivered.  `avg_launch_ms` is what the persistent kernel stamped itself (first workgroup's
+            # start to last wave's end on the chip's 100 MHz clock: the span rocprofv3's kernel trace reports); the end of one launch
+            # overlaps the start of the next, so the sum of the launches is a little more than the region.  Per launch: `per_launch`.
             r, why = roofline_from_profile(PIPE_KERNEL[pipe], workload, rays_local, elapsed)
             if r:
                 prof = r["prof"]
@@ -426,7 +429,8 @@ def main():
                 pl, _ = roofline_from_profile(PIPE_KERNEL[pipe], workload, rays_per_launch, sec_per_launch)
                 rf["per_launch"] = {"avg_launch_ms": kernel_ms / launches, "valu_frac": pl["valu_frac"], "hbm_frac": pl["hbm_frac"],
                                     "hbm_gbs": pl["hbm_rate"],
-                                    "note": "HIP-event duration of each launch on its own stream; two launches are in flight at a time, so "
+                                    "note": "in-kernel span of each launch (first workgroup's start to last wave's end, 100 MHz clock); the end of "
+                                            "one launch overlaps the start of the next and the resolve of the render before runs beside it, so "
                                             "this is not the chip's rate (the timed-region figures above are)"}
                 if serial_ms:
                     sr, _ = roofline_from_profile(PIPE_KERNEL[pipe], workload, rays_local / args.steps, serial_ms * 1e-3)

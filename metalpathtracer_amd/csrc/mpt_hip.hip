@@ -14,6 +14,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <map>
 #include <memory>
 #include <exception>
@@ -82,6 +84,7 @@ struct Lane {
     size_t ring_waves = 0;
     OtRings ot_ring = {};        // ... and its rings (MPT_OT_RINGS per wave)
     size_t ot_ring_waves = 0;
+    uint32_t announced_id = 0;   // launch id of the lane's last trace kernel that announces its residency (0: none)
     bool in_flight = false;      // enqueued by mpt_render_async, not yet collected
     bool timed = false;
 };
@@ -95,7 +98,9 @@ struct mpt_ctx {
     hipEvent_t last_traced = nullptr;    // behind the last trace kernel enqueued (either lane): the next trace kernel waits for it (lane_order)
     int resolve_wgs_per_cu = 2;          // MPT_RESOLVE_WGS: workgroups of 256 per CU of a resolve that runs beside a trace kernel (0 = as many as pixels / 256)
     bool sync_render = false;            // inside mpt_render / mpt_draw: nothing else is in flight, the resolve may take the whole chip
-    int lane_order = 1;                  // MPT_LANE_ORDER: bit 0 = trace kernels run one after the other, bit 1 = lane 0's stream has the higher priority
+    uint32_t launch_seq = 0;             // launch ids of the trace kernels (never 0)
+    Lane* last_trace_lane = nullptr;     // lane of the last trace kernel enqueued
+    int lane_order = 5;                  // MPT_LANE_ORDER: bit 0 = the event chain between trace kernels, bit 2 = the residency gate for overlapping k_wavelocal renders (run_pass), bit 1 = lane 0's stream has the higher priority (no effect measured)
     hipEvent_t ev_sum_op = nullptr;      // recorded behind mpt_clear_sum
     hipDeviceProp_t prop;
     std::string err;
@@ -174,7 +179,8 @@ static const void* ordered_kernel(bool count, bool all_lds) {
     return all_lds ? (const void*)k_ordered<false, true> : (const void*)k_ordered<false, false>;
 }
 
-static const void* wavelocal_kernel(bool count, bool all_lds) {
+static const void* wavelocal_kernel(bool count, bool all_lds, bool corun) {
+    if (corun && !count) return all_lds ? (const void*)k_wavelocal_corun<true> : (const void*)k_wavelocal_corun<false>;
     if (count) return all_lds ? (const void*)k_wavelocal<true, true> : (const void*)k_wavelocal<true, false>;
     return all_lds ? (const void*)k_wavelocal<false, true> : (const void*)k_wavelocal<false, false>;
 }
@@ -313,7 +319,8 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
         for (int a = 0; a < 2; ++a) {
             hipFuncSetAttribute(step_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute(mega_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(wavelocal_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(wavelocal_kernel(c, a, false), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (!c) hipFuncSetAttribute(wavelocal_kernel(false, a, true), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
     for (int c = 0; c < 2; ++c)
         for (int a = 0; a < 2; ++a) hipFuncSetAttribute(ordered_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1137,8 +1144,11 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     size_t lds = (size_t)ctx->n_lds_nodes * 32 + (size_t)ctx->n_lds_prims * 48 + MPT_LDS_EXTRA;
     int per_cu = 0;
     const bool all_lds = ctx->n_lds_nodes == ctx->n_nodes;
+    // a render that overlaps others (mpt_render_async) runs the variant of the wave-local kernel that leaves room on the CU for the
+    // resolve of the render before it (k_wavelocal_corun); only then may the end of one pass overlap the start of the next (below)
+    const bool corun = (ctx->lane_order & 4) && !ctx->sync_render && pipeline == MPT_PIPE_WAVELOCAL && !count_flag(p);
     const void* kfun = pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
-                       : pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds)
+                       : pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds, corun)
                        : pipeline == MPT_PIPE_ORDERED  ? ordered_kernel(count_flag(p), ctx->ot_lds_nodes == ctx->n_acc_nodes)
                                                         : step_kernel(count_flag(p), all_lds);
     // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel, mpt_ordered.h: 1024)
@@ -1160,11 +1170,41 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     const int grid = ctx->prop.multiProcessorCount * per_cu;
     hipStream_t st = L.stream;
     *L.h_done = 0;
-    // Trace kernels are persistent and sized for the whole chip: two of them must never be dispatched side by side (each would hold
+    // Trace kernels are persistent and sized for the whole chip: two of them must never be DISPATCHED side by side (each would hold
     // half of the workgroup slots for its whole life — measured: 21.7 ms per 256-spp step instead of 16.8), and which of two pending
-    // launches the hardware starts is not ours to choose.  So a trace kernel waits for the one enqueued before it, on whichever lane;
-    // what the second lane overlaps with it is everything else: the resolve of the render before, the statistics copy, the host.
-    if ((ctx->lane_order & 1) && ctx->last_traced && ctx->last_traced != L.ev_traced) HIPCHK(hipStreamWaitEvent(st, ctx->last_traced, 0));
+    // launches the hardware starts is not ours to choose.  Two ways to keep them apart:
+    //  * the chain: a trace kernel waits for the event behind the one enqueued before it, on whichever lane — strictly one after the
+    //    other; what the second lane overlaps is the resolve of the render before, the statistics copy, the host;
+    //  * the gate (renders of k_wavelocal_corun): this launch is SUBMITTED only once the trace kernel before it has announced that
+    //    all its workgroups are resident (announce_resident; the host waits here, at most for the render that is running) — from then
+    //    on this kernel's workgroups can only take the places the others give up as they finish: the end of one pass overlaps the
+    //    start of the next, and the resolve runs in the room the variant leaves.  Without the announcement within 200 ms (a kernel
+    //    that does not announce, a foreign kernel holding the chip): the chain.
+    bool need_chain = (ctx->lane_order & 1) != 0;
+    if (corun && ctx->last_trace_lane && ctx->last_trace_lane != &L) {
+        Lane& O = *ctx->last_trace_lane;
+        bool resident = false;
+        if (O.announced_id != 0u) {
+            const volatile uint32_t* flag = (const volatile uint32_t*)O.h_done + MPT_HOST_RESIDENT;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                if (*flag == O.announced_id || hipEventQuery(O.ev_traced) == hipSuccess) {   // resident (or even finished)
+                    resident = true;
+                    break;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+                std::this_thread::yield();
+            }
+        }
+        need_chain = !resident;
+    }
+    if (need_chain && ctx->last_traced && ctx->last_traced != L.ev_traced) HIPCHK(hipStreamWaitEvent(st, ctx->last_traced, 0));
+    pp.launch_id = 0u;
+    if (pipeline == MPT_PIPE_WAVELOCAL || pipeline == MPT_PIPE_ORDERED) {
+        if (++ctx->launch_seq == 0u) ctx->launch_seq = 1u;
+        pp.launch_id = ctx->launch_seq;
+    }
+    L.announced_id = pp.launch_id;
     hipLaunchKernelGGL(k_begin_pass, dim3(1), dim3(64), 0, st, L.d_desc, L.d_ctr, (uint32_t)pass_paths, slots_items,
                        (volatile uint32_t*)dev_done, pipeline == MPT_PIPE_WAVEFRONT ? 0 : 1);
     if (pipeline != MPT_PIPE_WAVEFRONT) {
@@ -1218,9 +1258,10 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
             HIPCHK(hipEventRecord(e1, st));
             L.pending_timed.emplace_back(e0, e1);
         }
-        if (ctx->lane_order & 1) {
+        if (ctx->lane_order & 5) {   // (always, unless MPT_LANE_ORDER=0)
             HIPCHK(hipEventRecord(L.ev_traced, st));
             ctx->last_traced = L.ev_traced;
+            ctx->last_trace_lane = &L;
         }
         ctx->stats.iterations += 1;
         return MPT_OK;
@@ -1305,12 +1346,16 @@ static int collect_lane(mpt_ctx* ctx, Lane& L) {
     HIPCHK(hipStreamSynchronize(L.stream));
     L.in_flight = false;
     const PassDesc& hd = *L.h_desc;
+    // duration of the trace kernels: what the persistent kernels stamped themselves (first workgroup's start to last wave's end on the
+    // 100 MHz clock, note_wave_exit) — the event pairs of overlapping renders include the time a launch waits behind the running kernel
+    float ev_ms = 0;
     for (auto& pr : L.pending_timed) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
-        ctx->stats.trace_kernel_ms += ms;
+        ev_ms += ms;
         ctx->stats.trace_launches += 1;
     }
+    ctx->stats.trace_kernel_ms += hd.trace_ticks != 0 && !L.pending_timed.empty() ? (double)hd.trace_ticks * 1e-5 : (double)ev_ms;
     L.pending_timed.clear();
     L.ev_used = 0;
     if (L.timed) {

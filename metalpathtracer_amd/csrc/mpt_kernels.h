@@ -42,15 +42,20 @@ struct PassDesc {
     uint32_t done, overflow, iterations;
     unsigned long long paths, rays, node_visits, aabb_hits, prim_tests, node_iters, prim_iters, leaf_phases;
     unsigned long long flagged, parked;  // closest-first pipeline: rays handed to the reference-order walk / parked for the tree
+    unsigned long long trace_ticks;      // persistent trace kernels: first workgroup's start to last wave's end, in 100 MHz ticks, summed over the launches (note_wave_exit)
+    unsigned long long t_first;          // ... the start of the running launch (announce_resident)
 };
-#define MPT_DESC_COUNTERS 10
+#define MPT_DESC_COUNTERS 11   // paths .. trace_ticks: cleared behind every statistics copy
 
 // Atomic counters live on lines of their own (MPT_CTR_STRIDE words apart): device-scope atomics are
 // executed at the memory side, and counters that share a line serialise there.
 #define MPT_CTR_STRIDE 1024u  // in uint32 words = 4 KiB
 #define MPT_CTR_CURSOR(g) ((g) * MPT_CTR_STRIDE)
 #define MPT_CTR_OUT(s) ((MPT_NGROUP + (s)) * MPT_CTR_STRIDE)
-#define MPT_CTR_WORDS ((MPT_NGROUP + MPT_NSHARD) * MPT_CTR_STRIDE)
+#define MPT_CTR_STARTED ((MPT_NGROUP + MPT_NSHARD) * MPT_CTR_STRIDE)   // workgroups of the trace kernel that have started (announce_resident)
+#define MPT_CTR_EXITED ((MPT_NGROUP + MPT_NSHARD + 1u) * MPT_CTR_STRIDE)   // waves of the trace kernel that have finished (note_wave_exit)
+#define MPT_CTR_WORDS ((MPT_NGROUP + MPT_NSHARD + 2u) * MPT_CTR_STRIDE)
+#define MPT_HOST_RESIDENT 8u   // word of the lane's pinned `done` block that receives the launch id once every workgroup of the launch is resident
 
 struct PassParams {
     SceneDev scene;
@@ -68,6 +73,7 @@ struct PassParams {
     uint32_t s_shift;            // log2(S) when S is a power of two, else 0xFF
     const uint32_t* tile_xy;     // this rank's tiles in processing order: x | y << 16
     uint32_t rank, nranks;
+    uint32_t launch_id;          // != 0: the last workgroup to start writes it to host_done[MPT_HOST_RESIDENT] (announce_resident)
     uint32_t tile_magic;         // != 0: the rank's k-th tile is tile T = k * nranks + rank in row-major order (tile order 0) and
                                  // T / tiles_x = umulhi(T, tile_magic) exactly (the host checks the range): path -> pixel needs no table load
     ShadeParams sp;
@@ -378,9 +384,35 @@ __device__ void advance_desc(PassDesc* d, uint32_t* ctr, volatile uint32_t* host
     if (host_done) *host_done = d->done | (d->overflow << 1);
 }
 
+// A persistent trace kernel tells the host when ALL its workgroups are resident (one thread per workgroup calls this first thing): from
+// then on the workgroups of a kernel launched behind it can only take the slots its own workgroups give up as they finish — the
+// overlap of the end of one pass with the start of the next that mpt_render_async wants — and never sit side by side with them from
+// the start, each kernel on half of the chip for its whole life.
+__device__ __forceinline__ void announce_resident(const PassParams& pp) {
+    if (pp.launch_id == 0u) return;
+    const uint32_t before = atomicAdd(&pp.ctr[MPT_CTR_STARTED], 1u);
+    if (before == 0u) __hip_atomic_store(&pp.desc->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == gridDim.x)
+        __hip_atomic_store((uint32_t*)pp.host_done + MPT_HOST_RESIDENT, pp.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ... and how long it ran: the last wave to finish adds (now - start of the first workgroup) to the descriptor, on the chip's 100 MHz
+// clock.  With renders that overlap, a HIP event in front of a launch fires when the launch is QUEUED behind the running kernel, not
+// when it starts: event pairs then read 25-29 ms for a kernel that runs 16.6 (and the kernel trace of rocprofv3 says 16.6).
+__device__ __forceinline__ void note_wave_exit(const PassParams& pp) {
+    if (pp.launch_id == 0u || (threadIdx.x & 63u) != 0u) return;
+    const uint32_t before = atomicAdd(&pp.ctr[MPT_CTR_EXITED], 1u);
+    if (before + 1u == gridDim.x * (blockDim.x >> 6)) {
+        const unsigned long long t0 = __hip_atomic_load(&pp.desc->t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&pp.desc->trace_ticks, (unsigned long long)__builtin_amdgcn_s_memrealtime() - t0);
+    }
+}
+
 __global__ void k_begin_pass(PassDesc* d, uint32_t* ctr, uint32_t total_paths, uint32_t slots_items,
                              volatile uint32_t* host_done, int path_cursors) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctr[MPT_CTR_STARTED] = 0u;
+    ctr[MPT_CTR_EXITED] = 0u;
     if (path_cursors) {  // single-launch pipelines: the cursors count path ids, one contiguous range per group
         d->total_paths = total_paths;  // overflow stays sticky until the host has read it (enqueue_stats_copy clears it)
         for (uint32_t g = 0; g < MPT_NGROUP; ++g) ctr[MPT_CTR_CURSOR(g)] = 0u;
@@ -622,14 +654,37 @@ struct WaveBudgets {
 #define MPT_WL_THREADS(ALL_LDS) MPT_WL_THREADS_N
 #define MPT_WL_WAVES(ALL_LDS) MPT_WL_WAVES_N
 template <bool COUNT, bool ALL_LDS>
+__device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveRings& ring, const WaveBudgets& budgets, uint32_t wl_block, uint32_t wl_min,
+                                               uint32_t wl_div);
+template <bool COUNT, bool ALL_LDS>
 __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) void k_wavelocal(PassParams pp, WaveRings ring, WaveBudgets budgets,
-                                                                 uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
+                                                                                             uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
+    wavelocal_body<COUNT, ALL_LDS>(pp, ring, budgets, wl_block, wl_min, wl_div);
+}
+// The same kernel held to 96 scalar registers, for renders that overlap (mpt_render_async).  A wave's scalar registers are allocated
+// in blocks of 16 plus 16: with the 102 the compiler takes when it is free to, six waves per SIMD hold 6 x 128 = 768 of the SIMD's
+// 800 and NOTHING else can start on the CU — not the resolve of the render before, not one wave of anybody's kernel (measured: a
+// one-element torch kernel launched beside the resident trace kernel waits 13-15 ms for it to end; tools/gpu_corun.py).  At <= 96 it
+// is 6 x 112 = 672 and 128 are left: the resolve's two waves per SIMD run beside it.  13 more scalar values live in VGPR lanes for
+// that: a render on its own is 1.7 % slower with this variant (17.5 against 17.2 ms), which is why mpt_render keeps the other one.
+#ifndef MPT_WL_CORUN_SGPRS
+#define MPT_WL_CORUN_SGPRS 96
+#endif
+template <bool ALL_LDS>
+__global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) __attribute__((amdgpu_num_sgpr(MPT_WL_CORUN_SGPRS)))
+void k_wavelocal_corun(PassParams pp, WaveRings ring, WaveBudgets budgets, uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
+    wavelocal_body<false, ALL_LDS>(pp, ring, budgets, wl_block, wl_min, wl_div);
+}
+template <bool COUNT, bool ALL_LDS>
+__device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveRings& ring, const WaveBudgets& budgets, uint32_t wl_block, uint32_t wl_min,
+                                               uint32_t wl_div) {
     extern __shared__ float4 lds_nodes_raw[];
     // what only some steps need goes to LDS, behind the scene image (the 256-byte descriptor area of MPT_LDS_EXTRA), instead of
     // living in scalar registers across the whole step loop: the camera (14 words, primary steps) and the ring budgets (10 words,
     // ring steps).  The loop needs more scalar registers than the 102 a wave has; every value kept out of it is one spill less.
     const uint32_t cfg_off = pp.scene.lds_mat_off + 2u * MPT_LDS_MATS_N;   // in float4 units
     if (threadIdx.x == 0) {
+        announce_resident(pp);
         lds_nodes_raw[cfg_off + 0] = make_float4(pp.cam.x, pp.cam.y, pp.cam.z, pp.W);
         lds_nodes_raw[cfg_off + 1] = make_float4(pp.first.x, pp.first.y, pp.first.z, pp.H);
         lds_nodes_raw[cfg_off + 2] = make_float4(pp.vu.x, pp.vu.y, pp.vu.z, 0.0f);
@@ -993,6 +1048,7 @@ __global__ __launch_bounds__(MPT_WL_THREADS(ALL_LDS), MPT_WL_WAVES(ALL_LDS)) voi
 #endif
     MPT_CLOCK_END();
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
+    note_wave_exit(pp);
 }
 
 // sum[pixel] += sum over the pass's samples (in sample order) of the clamped per-sample colour.

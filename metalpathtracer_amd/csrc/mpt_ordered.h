@@ -765,6 +765,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
     // (as in k_wavelocal, mpt_kernels.h)
     const uint32_t cfg_off = pp.scene.lds_mat_off + 2u * MPT_LDS_MATS_N;
     if (threadIdx.x == 0) {
+        announce_resident(pp);
         lds_raw[cfg_off + 0] = make_float4(pp.cam.x, pp.cam.y, pp.cam.z, pp.W);
         lds_raw[cfg_off + 1] = make_float4(pp.first.x, pp.first.y, pp.first.z, pp.H);
         lds_raw[cfg_off + 2] = make_float4(pp.vu.x, pp.vu.y, pp.vu.z, 0.0f);
@@ -1181,6 +1182,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
 #endif
     MPT_CLOCK_END();
     flush_stats<COUNT>(pp.desc, n_rays, n_paths, wc);
+    note_wave_exit(pp);
     {
         unsigned long long a = n_flagged, b = n_parked;
         for (int off = 32; off > 0; off >>= 1) {

@@ -16,13 +16,18 @@ cam = dict(pos=(0.0, 1.0, 3.4), fwd=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), vfov=4
 ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount(), cam=cam))
 spp = int(os.environ.get("SPP", "16")); pipe = int(os.environ.get("PIPE", "1")); depth = int(os.environ.get("DEPTH", "8"))
 shards = int(os.environ.get("SHARDS", "1")); bsdf = int(os.environ.get("BSDF", "0"))   # SHARDS=8: rank 0's 1/8 tile shard; BSDF 1 = Scatter.h
+launch = "async" if os.environ.get("ASYNC") else "sync"   # ASYNC=1: mpt_render_async + mpt_wait, one render at a time — the kernel variant bench.py's timed steps run (k_wavelocal_corun)
 import json
 print("WORKLOAD " + json.dumps(dict(scene=scene, width=W, height=H, spp=spp, depth=depth, pipeline=pipe, bvh=int(os.environ.get("BVH", "0")),
-                                    prims=sc.getPrimitiveCount(), shards=shards, bsdf=bsdf, env=capi.knob_env(),
+                                    prims=sc.getPrimitiveCount(), shards=shards, bsdf=bsdf, launch=launch, env=capi.knob_env(),
                                     **capi.build_id())), flush=True)
 for rep in range(int(os.environ.get("REPS", "2"))):
     ctx.clear_sum(); ctx.reset_stats()
-    ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, pipeline=pipe, slots_per_iter=int(os.environ.get("SLOTS", "0")),
-               shard_rank=0, shard_count=shards)
+    kw = dict(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, pipeline=pipe, slots_per_iter=int(os.environ.get("SLOTS", "0")),
+              shard_rank=0, shard_count=shards)
+    if launch == "async":
+        ctx.render_async(**kw); ctx.wait()
+    else:
+        ctx.render(**kw)
     st = ctx.stats()
     print("pipe %d spp %d depth %d: total_ms %.2f trace_ms %.2f launches %d rays %d -> %.1f Mrays/s" % (pipe, spp, depth, st["total_ms"], st["trace_kernel_ms"], st["trace_launches"], st["rays"], st["rays"] / st["total_ms"] / 1e3), flush=True)

@@ -7,7 +7,7 @@ TAG=${1:-r04}; PART=${2:-all}    # part 1: counter passes + the bench lines; par
 ROOT=${GRAFT_REPO_ROOT:-$PWD}; OUT=$ROOT/gpurun_out; mkdir -p $OUT; LIB=$ROOT/metalpathtracer_amd/lib
 if [ "$PART" != 2 ]; then
 # one counter profile per workload of the bench line (the headline step and its four extras) + the two cross runs of round 3
-BVH=3 PIPE=2 bash tools/pmc_round.sh ${TAG}wl k_wavelocal > $OUT/${TAG}_pmc_wl.log 2>&1 || exit 1
+BVH=3 PIPE=2 ASYNC=1 bash tools/pmc_round.sh ${TAG}wl k_wavelocal > $OUT/${TAG}_pmc_wl.log 2>&1 || exit 1   # (the variant the timed steps run: k_wavelocal_corun)
 BVH=0 PIPE=2 bash tools/pmc_round.sh ${TAG}wlref k_wavelocal > $OUT/${TAG}_pmc_wlref.log 2>&1 || exit 1
 SCENE=cornell.xml CAM=cornell BVH=3 PIPE=2 bash tools/pmc_round.sh ${TAG}cor k_wavelocal > $OUT/${TAG}_pmc_cor.log 2>&1 || exit 1
 SCENE=bunny20.xml BVH=3 SPP=256 PIPE=3 bash tools/pmc_round.sh ${TAG}otb k_ordered > $OUT/${TAG}_pmc_otb.log 2>&1 || exit 1
