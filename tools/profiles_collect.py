@@ -39,10 +39,22 @@ if os.path.exists(trace):
     b = json.loads(line)
     K, Wm = b["steps"], b["warmup"]
     labels = ["lane set-up"] * 2 + ["warm-up"] * Wm + ["timed step"] * K + ["serial render"] * min(3, K) + ["extra: cornell.xml"] * 3 + ["extra: bunny20.xml"] * 3 + ["extra: scene.xml on the reference's tree"] * 3 + ["extra: config4 shard"] * 3
+    t0 = int(rows[0]["Start_Timestamp"])
     launches = [{"kernel": r["Kernel_Name"].split("(")[0].replace("void ", ""), "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6,
+                 "start_ms": (int(r["Start_Timestamp"]) - t0) / 1e6, "end_ms": (int(r["End_Timestamp"]) - t0) / 1e6,
                  "what": labels[i] if i < len(labels) else "?"} for i, r in enumerate(rows)]
-    timed = [x["ms"] for x in launches if x["what"] == "timed step"]
+    timed = [x for x in launches if x["what"] == "timed step"]
+    first = launches.index(timed[0]) if timed else 0
+    ends = [launches[first - 1]["end_ms"]] + [x["end_ms"] for x in timed] if timed and first > 0 else []
     json.dump({"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d" % (K, Wm),
-               "timed_steps_avg_ms": sum(timed) / max(1, len(timed)), "bench_line_avg_launch_ms": b["roofline"]["avg_launch_ms"],
+               "note": "ms = End - Start of the kernel trace.  The timed steps are submitted while the launch before them is still running (mpt_render_async: "
+                       "a launch is submitted as soon as the one before it is fully resident, DESIGN.md 6), and the trace's Start is the DISPATCH of the "
+                       "launch, not the start of its first wave: for those launches End - Start includes the wait behind the resident kernel.  What the "
+                       "chip did is the spacing of the ENDs (timed_steps_end_spacing_avg_ms) and the span the kernel stamps itself "
+                       "(bench_line_avg_launch_ms: first workgroup's start to last wave's end on the 100 MHz clock); launches issued one at a time "
+                       "(set-up, serial renders, extras) read the same in all three.",
+               "timed_steps_avg_ms": sum(x["ms"] for x in timed) / max(1, len(timed)),
+               "timed_steps_end_spacing_avg_ms": (ends[-1] - ends[0]) / (len(ends) - 1) if len(ends) > 1 else None,
+               "bench_line_avg_launch_ms": b["roofline"]["avg_launch_ms"], "bench_line_ms_per_step": b["ms_per_step"],
                "launches": launches}, open(os.path.join(P, tag + "_bench_launches.json"), "w"), indent=1)
 print(sorted(f for f in os.listdir(P) if f.startswith(tag)))
