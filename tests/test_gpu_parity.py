@@ -502,6 +502,41 @@ def test_camera_move_resets_accumulation_and_reseeds(gpu_ctx):
     r.close()
 
 
+@pytest.mark.parametrize("lane_order", ["5", "1", "0"])
+def test_pipelined_renders_give_the_serial_image_under_every_lane_rule(lane_order, monkeypatch):
+    """mpt_render_async without the counting flag runs k_wavelocal_corun behind the residency gate (MPT_LANE_ORDER=5, the default),
+    behind the event chain alone (1) or on independent lanes (0): twelve pipelined renders (a trace kernel long enough for the gate to
+    wait on, a serial render and a re-sharding in between) must leave the HDR sum bit-identical to the same renders issued one at a
+    time, and the kernels' own time stamps must add up to something sane."""
+    from metalpathtracer_amd import capi
+    monkeypatch.setenv("MPT_LANE_ORDER", lane_order)
+    ctx = capi.Context(0)
+    try:
+        buf, uo = setup(ctx, "scene.xml", 960, 540)
+        kw = dict(rng_mode=capi.RNG_PHILOX, max_depth=8, seed=(7, 1))
+        def sequence(issue):
+            ctx.clear_sum(); ctx.reset_stats()
+            for k in range(6): issue(sample_begin=8 * k, sample_count=8, **kw)
+            ctx.render(sample_begin=48, sample_count=4, **kw)                      # a synchronous render in between
+            for k in range(3): issue(sample_begin=52 + 2 * k, sample_count=2, shard_rank=k % 2, shard_count=2, **kw)
+            for k in range(3): issue(sample_begin=52 + 2 * k, sample_count=2, shard_rank=1 - k % 2, shard_count=2, **kw)
+            ctx.wait()
+            return ctx.read_sum(), ctx.stats()
+        serial, s_serial = sequence(ctx.render)
+        piped, s_piped = sequence(ctx.render_async)
+        np.testing.assert_array_equal(serial.view(np.uint32), piped.view(np.uint32))
+        assert s_serial["rays"] == s_piped["rays"] and s_serial["paths"] == s_piped["paths"]
+        assert s_piped["trace_launches"] == 7          # (the synchronous render in between restarts the timing statistics: itself + 6)
+        # the kernels' own spans (first workgroup's start to last wave's end), summed: the seven launches trace 14 of the 64 samples
+        assert 0 < s_piped["trace_kernel_ms"] < 200.0
+        ref, _ = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, max_depth=8, accumulate=1, sample_count=2, seed=(7, 1), threads=8)
+        ctx.clear_sum()
+        ctx.render_async(sample_begin=0, sample_count=1, **kw); ctx.render_async(sample_begin=1, sample_count=1, **kw)
+        np.testing.assert_array_equal(ctx.read_sum().view(np.uint32), ref.view(np.uint32))
+    finally:
+        ctx.close()
+
+
 def test_async_renders_overlap_and_match_the_serial_result(gpu_ctx):
     """mpt_render_async: consecutive renders overlap on two lanes; the HDR sum must be bit-identical to serial
     mpt_render calls (resolves are chained in submission order) and the statistics must add up after mpt_wait."""
