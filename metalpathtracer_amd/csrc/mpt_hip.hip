@@ -38,9 +38,9 @@
 // render's trace kernel fills the CUs that the previous one's tail (and its resolve) leave idle (measured with two
 // contexts: +11 % at 1080p x 256 spp, +15 % for a 1/8 tile shard).  Resolves are chained in submission order, so the
 // HDR sum is bit-identical to the serial schedule.
-// Box-test trips granted per step of ring 0..LEVELS-2 (the last ring runs to completion).  Measured on scene.xml at
-// 1080p x 256 spp: 8/20/50/125 -> 29.3 ms, 8/24/72/inf -> 30.4, 8/16/32/64 -> 30.2, 8/16/32/inf -> 31.8, 8/12/24/48 -> 31.3:
-// bounce rays are heavy-tailed at every scale, so every ring needs a budget near the median of what its rays still need.
+// Box-test trips granted per step of ring 0..LEVELS-2 (the last ring runs to completion).  Rounds 1-3 (five rings), scene.xml at
+// 1080p x 256 spp: 8/20/50/125 -> 29.3 ms, 8/24/72/inf -> 30.4, 8/16/32/64 -> 30.2, 8/16/32/inf -> 31.8, 8/12/24/48 -> 31.3.
+// Round 4 (two rings, mpt_kernels.h): only ring 0's budget is left — 6 / 8 / 12 / 16 / 24: 17.01 / 16.88 / 17.11 / 17.49 / 18.26 ms.
 static WaveBudgets default_budgets() {
     WaveBudgets w;
     const uint32_t ladder[] = {8, 20, 50, 125, 300, 700, 1600};

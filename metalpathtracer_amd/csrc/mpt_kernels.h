@@ -509,14 +509,18 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 // any result: every ray writes only its own path's slot.
 // Why budgets: a wave runs as long as its slowest lane, and bounce rays are heavy-tailed on this kind of scene — 88 %
 // need <= 8 box tests, 10 % need 30-160 (they cross the mesh): a full wave of bounce rays used only 14 % of its
-// box-test lane slots.  Budgets 8/20/50/125/inf (mpt_hip.hip: default_budgets) sort rays by remaining work, so every
-// step runs rays of similar length (measured: box-test lane slots per ray 37.8 -> 17.8, VALU instructions per ray
-// 40 -> 24).  A parked ray resumes with exactly the state it stopped with and sees the
-// same sequence of tests: results are bit-identical.
+// box-test lane slots.  Budgets sort rays by remaining work, so every step runs rays of similar length (rounds 1-3: a ladder
+// 8/20/50/125/inf over five rings, box-test lane slots per ray 37.8 -> 17.8, VALU instructions per ray 40 -> 24).  A parked ray
+// resumes with exactly the state it stopped with and sees the same sequence of tests: results are bit-identical.
+// Round 4, TWO rings: ring 0 (hits; their bounce rays get 8 trips) and ONE ring of unfinished walks that runs without a budget
+// but regroups — a step ends once fewer than 24 of its lanes still traverse and the stragglers go back into the same ring.  Since
+// ring 0 holds hits that are shaded at full width, the deeper ladder only cost scalar registers and leftovers at the end of a
+// pass: 5 -> 2 rings is 17.69 -> 16.88 ms on scene.xml (3 rings 17.4-17.6, 4 rings 17.5-17.7, ONE ring = no budget at all 26.1);
+// a 1/8 shard's step 2.46 -> 2.36 ms (a wave drains 2 x ~32 leftover rays, not 5 x ~32).
 // Capacity: steps on rings never increase the total number of queued rays (64 out, <= 64 in) and a primary step
-// (+<= 64) runs only when every ring holds < 64, so the total never exceeds 64 * LEVELS + 64 = 384 < MPT_WL_RING.
+// (+<= 64) runs only when every ring holds < 64, so the total never exceeds 64 * LEVELS + 64 < MPT_WL_RING.
 #ifndef MPT_WL_LEVELS
-#define MPT_WL_LEVELS 5u
+#define MPT_WL_LEVELS 2u
 #endif
 #define MPT_WL_RING 512u       // records per ring
 #define MPT_LDS_MATS_N 32u     // materials staged in LDS (= MPT_LDS_MATS of mpt_hip.hip): the configuration block of k_wavelocal / k_ordered starts behind them

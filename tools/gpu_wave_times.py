@@ -37,12 +37,13 @@ print("drain per wave (us):  ", pc(end - exh))
 claim = (buf[:, 3] - t0).astype(np.float64) / 100.0
 print("last claim (us):      ", pc(claim))
 print("exhaust - last claim: ", pc(exh - claim))
+LEVELS = int(os.environ.get("LEVELS", "2"))   # MPT_WL_LEVELS of the build (mpt_kernels.h)
 late = np.argsort(exh)[-int(n * 0.02):]
 early = np.argsort(exh)[:int(n * 0.5)]
 def unpack(a): return np.stack([(a >> np.uint64(12 * k)) & np.uint64(0xFFF) for k in range(6)], 1).astype(np.int64)
 for name, sel in (("latest 2%", late), ("earliest 50%", early)):
-    st_ = unpack(buf[sel, 4]); lf = unpack(buf[sel, 5])[:, :5]
-    print(name, "steps after last claim [prim,L0..L4] mean", st_.mean(0).round(1), "left at exhaust [L0..L4] mean", lf.mean(0).round(1),
+    st_ = unpack(buf[sel, 4])[:, :LEVELS + 1]; lf = unpack(buf[sel, 5])[:, :LEVELS]
+    print(name, "steps after last claim [primary, ring 0..] mean", st_.mean(0).round(1), "left at exhaust [ring 0..] mean", lf.mean(0).round(1),
           "last blk mean %.0f" % buf[sel, 6].astype(np.float64).mean(), "exh-claim mean %.0f us" % (exh[sel] - claim[sel]).mean(), "drain mean %.0f" % (end[sel] - exh[sel]).mean())
 
 import json
@@ -62,8 +63,8 @@ print("  inside closest hit: box-test loop %.1f %%, leaf (primitive) loop %.1f %
 
 if flags:
     print("per step kind (COUNT build): steps, rays/step, done %, box trips/step, box lane utilisation, prim trips/step, prim lane utilisation, share of all box+prim wave trips")
-    names = ["primary", "ring 0", "ring 1", "ring 2", "ring 3", "ring 4", "drain"]
-    tot = (lv[:7, 1] * 26 + lv[:7, 3] * 70).sum()
+    names = ["primary"] + ["ring %d" % k for k in range(LEVELS)] + ["drain"]
+    tot = (lv[:len(names), 1] * 26 + lv[:len(names), 3] * 70).sum()
     for i, nm in enumerate(names):
         st_, bt, bw, pt, pw, rays, dn = lv[i, :7]
         wl = lv[i, 7]
