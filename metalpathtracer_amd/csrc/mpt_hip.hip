@@ -157,7 +157,10 @@ struct mpt_ctx {
     // guided path-id claims: max(wl_min, remaining / (wl_div * waves)).  wl_div, measured again after the kernels got faster
     // (serial 256-spp render of scene.xml, two runs): 16 -> 23.4-23.8 ms, 24 22.5, 32 22.3-22.4, 48 22.3-22.5, 64 22.3-22.4,
     // 128 22.5, 256 22.8; glass.xml, bunny x20, 32-spp and 640x360 renders move by +-1 % between 16 and 64
-    uint32_t wl_min = 64, wl_div = 32;
+    // wl_min = 0: by the size of the pass (run_pass) — the smallest claim is 64 path ids (one step) when a wave's share of the pass is
+    // small (a 1/8 shard: 11 k paths per wave) and up to 256 when it is large (a full 1080p x 256 spp pass: 86 k): scene.xml with 64 /
+    // 128 / 256 / 512 / 1024 -> 16.79-16.86 / 16.70 / 16.62-16.65 / 16.65 / 17.87 ms, the 1/8 shard's serial step 2.54 / - / 2.71 / 3.36
+    uint32_t wl_min = 0, wl_div = 32;
     uint32_t wl_block = MPT_WL_BLOCK;  // path ids a wave claims per atomic (multiple of 64)
     int wgs_per_cu = 0;  // 0 = as many as the occupancy query admits
     size_t lds_budget = 78 * 1024;  // per workgroup; two workgroups per CU share the 160 KiB
@@ -1233,6 +1236,10 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
                 L.ring_waves = waves;
             }
             uint32_t wl_block = ctx->wl_block, wl_min = ctx->wl_min, wl_div = ctx->wl_div;
+            if (wl_min == 0u) {   // (a wave's share of the pass / 16 Ki path ids, in steps of 64, between 64 and 256)
+                const uint64_t share = pass_paths / std::max<size_t>(1, waves);
+                wl_min = 64u * (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, share >> 14));
+            }
             if (pipeline == MPT_PIPE_ORDERED) {
                 if (waves > L.ot_ring_waves) {
                     free_ot_rings(L.ot_ring);
