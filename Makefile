@@ -13,7 +13,7 @@ LIBDIR    := $(PKG)/lib
 HIPFLAGS  ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Wno-pass-failed -fno-slp-vectorize
 HOSTFLAGS ?= -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wall -Wextra
 
-all: $(LIBDIR)/libmpt_hip.so host oracle
+all: $(LIBDIR)/libmpt_hip.so host oracle teststub
 
 $(LIBDIR)/libmpt_hip.so: $(PKG)/csrc/mpt_hip.hip $(wildcard $(PKG)/csrc/*.h) include/mpt.h
 	@mkdir -p $(LIBDIR)
@@ -25,7 +25,17 @@ host:
 oracle:
 	$(MAKE) --no-print-directory -C oracle
 
-clean:
-	rm -rf $(LIBDIR) oracle/_build oracle/_ref
+# test infrastructure: the librccl test double that lets the N > 1 collective path run on one GPU (tests/test_gpu_stub_rccl.py)
+teststub: tests/stub_rccl/_build/librccl.so.1 tests/holder/_build/libholdchip.so
+# ... and the foreign persistent kernel of the residency-gate test (tests/test_gpu_parity.py)
+tests/holder/_build/libholdchip.so: tests/holder/hold_chip.hip
+	@mkdir -p tests/holder/_build
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -shared -o $@ $<
+tests/stub_rccl/_build/librccl.so.1: tests/stub_rccl/stub_rccl.hip
+	@mkdir -p tests/stub_rccl/_build
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -shared -o $@ $<
 
-.PHONY: all host oracle clean
+clean:
+	rm -rf $(LIBDIR) oracle/_build oracle/_ref tests/stub_rccl/_build tests/holder/_build
+
+.PHONY: all host oracle teststub clean

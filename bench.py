@@ -15,7 +15,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel vs the two roofs it can be measured against: vector-ALU instruction issue (wave64
                 instructions x 2 cycles on a SIMD-32) and measured HBM traffic; `frac` is the larger of the two and
                 cannot exceed 1.  The per-ray instruction / byte figures come from the committed rocprofv3 --pmc passes of
-                the same build and workload (profiles/), scaled by this run's rays per launch and HIP-event launch time.
+                the same build and workload (profiles/), scaled by the rays of the K timed steps over the WALL time of the
+                timed region (the clock `value` is quoted on); per-launch and serial-render figures are secondary fields.
                 The SURVEY.md 8(d) algorithmic bytes per ray are kept under `algorithmic` (they price LDS-served BVH
                 reads as HBM and so exceed the HBM peak: not a bound).
   cpu_baseline  the CPU oracle (this repo's restatement of the reference algorithm; the reference has no CPU
@@ -67,8 +68,8 @@ def parse():
 def counter_profile(kernel, workload):
     """Per-launch counters of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_round.sh on
     tools/prof_run.py; PMC cannot be collected from inside this process).  A profile is used only if it was taken on THIS
-    workload (scene, size, spp, depth, tree builder, knobs) with THIS build (library or source sha256, capi.build_id): its
-    per-ray counters are then scaled by this run's rays per launch and HIP-event launch time.  Returns (per-ray figures or
+    workload (scene, size, spp, depth, tree builder, shard, BSDF mode, knobs) with THIS build (library or source sha256,
+    capi.build_id): its per-ray counters are then scaled by this run's rays and time (roofline_from_profile).  Returns (per-ray figures or
     None, {"profile_stale": true / "profile_missing": ..., ...}): nothing is guessed and nothing is swallowed."""
     import glob
     from metalpathtracer_amd import capi
@@ -82,6 +83,8 @@ def counter_profile(kernel, workload):
         if any(wl.get(k) != workload[k] for k in ("scene", "width", "height", "spp", "depth", "bvh", "env")):
             continue
         if wl.get("launch", "sync") != workload.get("launch", "sync"):   # mpt_render_async runs another variant of k_wavelocal than mpt_render
+            continue
+        if wl.get("shards", 1) != workload.get("shards", 1) or wl.get("bsdf", 0) != workload.get("bsdf", 0):   # (a 1/8 shard or Scatter.h BSDFs: other rays)
             continue
         rel = os.path.relpath(f, ROOT)
         if wl.get("source_sha256") != bid["source_sha256"] and wl.get("lib_sha256") != bid["lib_sha256"]:
@@ -230,7 +233,7 @@ def extra_workloads(ctx, capi, host, depth):
              "pipeline": PIPE_NAMES[pipe], "ms_per_render": best["total_ms"],
              "mrays_per_s": best["rays"] / best["total_ms"] / 1e3, "rays": best["rays"], "paths": best["paths"]}
         workload = {"scene": name if name != "config4" else "config4", "width": W, "height": H, "spp": spp, "depth": dep,
-                    "bvh": BVH_CODE[builder], "env": capi.knob_env()}
+                    "bvh": BVH_CODE[builder], "env": capi.knob_env(), "shards": shards, "bsdf": int(bsdf)}
         r, why = roofline_from_profile(PIPE_KERNEL[pipe], workload, best["rays"], best["total_ms"] * 1e-3)
         if r:
             e["roofline"] = {"kernel": PIPE_KERNEL[pipe], "bound": "valu" if r["valu_frac"] >= r["hbm_frac"] else "hbm",

@@ -162,15 +162,22 @@ int mpt_draw(mpt_ctx* ctx, const mpt_render_params* p);
  * (PathTracing.h:258) into the HDR sum buffer.  Synchronous; fills the timing fields of mpt_stats.  */
 int mpt_render(mpt_ctx* ctx, const mpt_render_params* p);
 
-/* The same, without waiting: enqueues the render and returns.  Up to two renders are in flight (a third call first
- * collects the oldest); their trace kernels overlap on the device — the next render fills the compute units that the
- * previous one's tail and resolve leave idle — while the updates of the HDR sum stay in submission order, so the
- * result is bit-identical to consecutive mpt_render calls.  mpt_wait collects everything in flight; statistics of
+/* The same, without waiting: checks the arguments, queues the render and RETURNS (microseconds: whatever a submission has to
+ * wait for — a free render lane, the trace kernel before it becoming resident — is waited for on the context's own submit thread,
+ * not on the caller's; at most 64 renders are queued, a 65th call waits for room).  Up to two renders are in flight on the device:
+ * their trace kernels overlap — the next render fills the compute units that the previous one's tail and resolve leave idle —
+ * while the updates of the HDR sum stay in submission order, so the result is bit-identical to consecutive mpt_render calls.
+ * mpt_wait collects everything queued and in flight and reports the first failure of a queued render; statistics of
  * asynchronous renders appear in mpt_get_stats after they were collected (trace_kernel_ms / total_ms / trace_launches
- * then accumulate until mpt_reset_stats or the next mpt_render).  Every other call that touches the scene, the size or
- * the sum buffer waits by itself.  This mirrors Metal's commit() without waitUntilCompleted (Renderer.cpp:308).      */
+ * then accumulate until mpt_reset_stats or the next mpt_render).  Every other call on the context first waits until the queue
+ * has been submitted (and those that touch the scene, the size or the sum buffer until the renders are done): the context is
+ * still driven by ONE caller thread.  This mirrors Metal's commit() without waitUntilCompleted (Renderer.cpp:253-266,307-308). */
 int mpt_render_async(mpt_ctx* ctx, const mpt_render_params* p);
 int mpt_wait(mpt_ctx* ctx);
+/* Diagnostics of the asynchronous path: out4 = {renders submitted by the submit thread, submissions that found the trace kernel
+ * before them resident (the residency gate), submissions that did not within 200 ms and fell back to the event chain (a foreign
+ * kernel holds the chip), the longest mpt_render_async call so far in microseconds of host time}.                                */
+int mpt_async_info(mpt_ctx* ctx, uint64_t out4[4]);
 
 /* HDR sum buffer (RGBA32F, W*H*4 floats, row-major, top-left origin).  The pointer is device
  * memory on the context's device, e.g. for an RCCL reduce by the caller.  mpt_set_sum_buffer lets
@@ -272,6 +279,11 @@ const char* mpt_comm_last_error(const mpt_comm* comm);
 int mpt_kat_pcg(mpt_ctx* ctx, const uint32_t* seeds, uint64_t n, uint32_t* hash_out, float* float_out);
 int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* ctr4, const uint32_t* key2, uint64_t n, uint32_t* out4);
 int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* sin_out, float* cos_out);
+/* The reciprocal of the hot path (1.0 / r.direction[i], PathTracing.h:61; 1 / a of the triangle test, :153-165): the kernels' short
+ * form (v_rcp_f32 + the compiler's own fma chain, without v_div_scale / v_div_fixup) against the correctly rounded division, over ALL
+ * 2^32 operands, on the device.  out4 = {mismatches inside the range the kernels use the short form in, operands in that range,
+ * mismatches outside it, operands outside it}; out4[0] must be 0.                                                                   */
+int mpt_kat_rcp(mpt_ctx* ctx, uint64_t* out4);
 
 #ifdef __cplusplus
 }

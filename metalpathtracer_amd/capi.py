@@ -24,9 +24,9 @@ STATUS = {0: "MPT_OK", 1: "MPT_ERR_INVALID_ARG", 2: "MPT_ERR_NO_DEVICE", 3: "MPT
 # every symbol include/mpt.h declares (tests/test_capi_symbols.py checks header <-> library <-> this list)
 SYMBOLS = (
     "mpt_create", "mpt_destroy", "mpt_last_error", "mpt_status_string", "mpt_upload_scene", "mpt_set_uniforms",
-    "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
+    "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_async_info", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
     "mpt_read_frame", "mpt_read_sum", "mpt_write_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
-    "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos",
+    "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos", "mpt_kat_rcp",
     "mpt_build_bvh", "mpt_build_and_upload", "mpt_download_bvh", "mpt_gpu_leaf_max", "mpt_build_info", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
     "mpt_comm_last_error",
 )
@@ -161,6 +161,8 @@ def load():
     L.mpt_kat_pcg.argtypes = [vp, up, C.c_uint64, up, fp]
     L.mpt_kat_philox.argtypes = [vp, up, up, C.c_uint64, up]
     L.mpt_kat_sincos.argtypes = [vp, fp, C.c_uint64, fp, fp]
+    L.mpt_kat_rcp.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.mpt_async_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -297,6 +299,11 @@ class Context:
     def wait(self):
         self._chk(self.L.mpt_wait(self.h), "mpt_wait")
 
+    def async_info(self):
+        out = (C.c_uint64 * 4)()
+        self._chk(self.L.mpt_async_info(self.h, out), "mpt_async_info")
+        return dict(zip(("submitted", "gate_resident", "gate_timeout", "call_us_max"), [int(v) for v in out]))
+
     def clear_sum(self):
         self._chk(self.L.mpt_clear_sum(self.h), "mpt_clear_sum")
 
@@ -429,3 +436,10 @@ class Context:
         c = np.empty_like(u)
         self._chk(self.L.mpt_kat_sincos(self.h, _fp(u), u.size, _fp(s), _fp(c)), "mpt_kat_sincos")
         return s, c
+
+    def kat_rcp(self):
+        """rcp_chain(x) vs the correctly rounded 1.0f / x over all 2^32 operands, on the device:
+        (mismatches inside the range the kernels use the chain in, operands in it, mismatches outside, operands outside)."""
+        out = (C.c_uint64 * 4)()
+        self._chk(self.L.mpt_kat_rcp(self.h, out), "mpt_kat_rcp")
+        return tuple(int(v) for v in out)

@@ -17,13 +17,30 @@
 
 using namespace MetalCppPathTracer;
 
+// what a checkpoint was accumulated FROM: FNV-1a over the packed primitive and material arrays (Scene::create*Buffer, spheres first)
+static unsigned long long sceneFingerprint(const Scene& sc) {
+    unsigned long long h = 0xcbf29ce484222325ull;
+    auto eat = [&](const void* p, size_t bytes) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    };
+    const size_t n = sc.getPrimitiveCount();
+    mpt::float4* prims = sc.createTransformsBuffer();
+    mpt::float4* mats = sc.createMaterialsBuffer();
+    eat(&n, sizeof n);
+    if (prims) eat(prims, n * 3 * sizeof(mpt::float4));
+    if (mats) eat(mats, n * 2 * sizeof(mpt::float4));
+    delete[] prims;
+    delete[] mats;
+    return h;
+}
 static void usage() {
     std::puts(
         "mpt_render --scene scene.xml [--asset-root DIR] [--width 1280] [--height 720]\n"
         "           [--spp 64] [--depth 32] [--seed 1] [--rng philox|literal] [--bsdf lambert|scatter|scatter-all]\n"
         "           [--pipeline auto|ordered|wavelocal|wavefront|megakernel] [--frames N] [--device 0] [--out image.pfm|image.ppm]\n"
         "           [--camera-pos x,y,z] [--camera-dir x,y,z] [--camera-up x,y,z] [--vfov degrees]\n"
-        "           [--gpus N] [--camera-path FILE [--out-dir runs]] [--bvh reference|binned|gpu|auto]\n"
+        "           [--gpus N | --devices a,b,...] [--camera-path FILE [--out-dir runs]] [--bvh reference|binned|gpu|auto]\n"
         "           [--checkpoint FILE] [--resume FILE]\n"
         "  --bvh             tree builder: the reference's sweep SAH (default with --rng literal, --frames and --camera-path:\n"
         "                    the drop-in behaviour) or auto (default for batch renders: the tree of every scene is built on the\n"
@@ -35,6 +52,7 @@ static void usage() {
         "  --frames N        run the reference's frame protocol (N draw() calls, running mean) instead of batch spp\n"
         "  --gpus N          batch mode on GPUs device .. device+N-1: 8x8 pixel tiles interleaved over the GPUs, one RCCL\n"
         "                    reduce(sum) of the HDR framebuffer onto the first (mpt_comm_create_all / mpt_reduce_sum)\n"
+        "  --devices a,b,..  the same on the listed device ordinals, one rank each (RCCL itself refuses an ordinal listed twice)\n"
         "  --camera-path F   headless replay of the reference's input handling (R/Window/ControllerView.mm:41-73): one\n"
         "                    line of F per frame, optionally prefixed by a repeat count, holding the keys\n"
         "                    w a s d space c (move), r (reset), `mouse dx dy`, `scroll dy`; every frame is one draw()\n"
@@ -132,12 +150,13 @@ static int playCameraPath(Renderer& r, OffscreenView& view, const std::string& p
 // Batch render on N GPUs driven by this one host thread (SURVEY.md 8e / include/mpt.h "multi-GPU"): every GPU gets the
 // scene, renders its interleaved tile shard asynchronously, and ONE ncclReduce(sum) lands the HDR sum on the first GPU.
 static int renderOnSeveralGpus(const std::string& scene, const std::string& assetRoot, const std::string& out, int width, int height,
-                               int spp, int device, int gpus, int bvh, mpt_render_params prm, const float* camPos, const float* camDir,
+                               int spp, const std::vector<int>& devices, int bvh, mpt_render_params prm, const float* camPos, const float* camDir,
                                const float* camUp, float vfov) {
     std::vector<std::unique_ptr<Renderer>> rs;
     mpt_comm* comm = nullptr;
+    const int gpus = static_cast<int>(devices.size());
     try {
-        for (int g = 0; g < gpus; ++g) rs.emplace_back(new Renderer(device + g, scene, assetRoot, bvh));
+        for (int g = 0; g < gpus; ++g) rs.emplace_back(new Renderer(devices[g], scene, assetRoot, bvh));
         if (camPos) Camera::position = mpt::float3(camPos[0], camPos[1], camPos[2]);
         if (camDir) Camera::forward = mpt::normalize(mpt::float3(camDir[0], camDir[1], camDir[2]));
         if (camUp) Camera::up = mpt::normalize(mpt::float3(camUp[0], camUp[1], camUp[2]));
@@ -162,7 +181,7 @@ static int renderOnSeveralGpus(const std::string& scene, const std::string& asse
             u.primitiveCount = rs[g]->scene()->getPrimitiveCount();
             u.triangleCount = rs[g]->scene()->getTriangleCount();
             if ((rc = mpt_set_uniforms(ctxs[g], &u)) || (rc = mpt_render_async(ctxs[g], &p)))
-                throw std::runtime_error(std::string("render on GPU ") + std::to_string(device + g) + ": " + mpt_last_error(ctxs[g]));
+                throw std::runtime_error(std::string("render on GPU ") + std::to_string(devices[g]) + ": " + mpt_last_error(ctxs[g]));
         }
         if ((rc = mpt_reduce_sum(comm, 0))) throw std::runtime_error(std::string("mpt_reduce_sum: ") + mpt_comm_last_error(comm));
         double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -198,6 +217,7 @@ int main(int argc, char** argv) {
     unsigned seed = 1;
     float camPos[3], camDir[3], camUp[3], vfov = 0.0f;
     bool havePos = false, haveDir = false, haveUp = false;
+    std::vector<int> deviceList;   // --devices a,b,...: the ordinals of a multi-GPU render, one rank each (default: --device .. --device + gpus - 1)
     mpt_render_params prm;
     std::memset(&prm, 0, sizeof prm);
     prm.rng_mode = MPT_RNG_PHILOX;
@@ -222,6 +242,18 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--frames") frames = std::atoi(next());
         else if (a == "--gpus") gpus = std::atoi(next());
+        else if (a == "--devices") {
+            for (const char* q = next(); *q;) {
+                char* end = nullptr;
+                const long v = std::strtol(q, &end, 10);
+                if (end == q || v < 0) {
+                    usage();
+                    return 2;
+                }
+                deviceList.push_back(static_cast<int>(v));
+                q = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (a == "--camera-path") cameraPath = next();
         else if (a == "--out-dir") outDir = next();
         else if (a == "--out") out = next();
@@ -268,8 +300,14 @@ int main(int argc, char** argv) {
     prm.max_depth = depth;
     prm.seed_lo = seed;
     if (bvh < 0) bvh = prm.rng_mode == MPT_RNG_LITERAL || frames > 0 || !cameraPath.empty() ? Renderer::BUILD_REFERENCE : Renderer::BUILD_AUTO;
-    if (gpus > 1) return renderOnSeveralGpus(scene, assetRoot, out, width, height, spp, device, gpus, bvh, prm, havePos ? camPos : nullptr,
-                                             haveDir ? camDir : nullptr, haveUp ? camUp : nullptr, vfov);
+    if (!deviceList.empty()) gpus = static_cast<int>(deviceList.size());
+    if (gpus > 1) {
+        if (deviceList.empty())
+            for (int g = 0; g < gpus; ++g) deviceList.push_back(device + g);
+        return renderOnSeveralGpus(scene, assetRoot, out, width, height, spp, deviceList, bvh, prm, havePos ? camPos : nullptr, haveDir ? camDir : nullptr,
+                                   haveUp ? camUp : nullptr, vfov);
+    }
+    if (deviceList.size() == 1) device = deviceList[0];
     try {
         Renderer r(device, scene, assetRoot, bvh);
         r.setRenderParams(prm);
@@ -295,20 +333,25 @@ int main(int argc, char** argv) {
             img = view.rgba;
         } else {
             // checkpoint / resume of the accumulation (the reference's running mean lives in a GPU-private texture and is lost with the
-            // process, R/Renderer/Renderer.cpp:236): header "MPTSUM1 W H samples seed rng depth\n" + W * H * 4 raw floats
+            // process, R/Renderer/Renderer.cpp:236): header "MPTSUM2 W H samples seed rng depth bsdf scene-hash\n" + W * H * 4 raw floats.
+            // The hash (FNV-1a over the packed primitive and material arrays) and the BSDF mode identify WHAT was accumulated: a resume on
+            // another scene or material model is refused instead of mixing sums.  Written to a temporary file and renamed over the target,
+            // so that a crash mid-write never destroys the checkpoint that --resume just read.
             uint32_t have = 0;
             r.clearSum();
+            const unsigned long long sceneHash = sceneFingerprint(*r.scene());
             if (!resume.empty()) {
                 FILE* f = std::fopen(resume.c_str(), "rb");
-                int w = 0, h = 0, rngm = 0, dep = 0;
+                int w = 0, h = 0, rngm = 0, dep = 0, bs = 0;
                 unsigned sd = 0;
-                if (!f || std::fscanf(f, "MPTSUM1 %d %d %u %u %d %d", &w, &h, &have, &sd, &rngm, &dep) != 6 || std::fgetc(f) != '\n') {
+                unsigned long long sh = 0;
+                if (!f || std::fscanf(f, "MPTSUM2 %d %d %u %u %d %d %d %llx", &w, &h, &have, &sd, &rngm, &dep, &bs, &sh) != 8 || std::fgetc(f) != '\n') {
                     if (f) std::fclose(f);
                     throw std::runtime_error("cannot read the checkpoint " + resume);
                 }
-                if (w != width || h != height || sd != seed || rngm != prm.rng_mode || dep != depth) {
+                if (w != width || h != height || sd != seed || rngm != prm.rng_mode || dep != depth || bs != prm.bsdf_mode || sh != sceneHash) {
                     std::fclose(f);
-                    throw std::runtime_error("the checkpoint " + resume + " was written with another size, seed, RNG or depth");
+                    throw std::runtime_error("the checkpoint " + resume + " was written with another scene, size, seed, RNG, BSDF mode or depth");
                 }
                 std::vector<float> sum(static_cast<size_t>(w) * h * 4);
                 const size_t got = std::fread(sum.data(), sizeof(float), sum.size(), f);
@@ -319,11 +362,16 @@ int main(int argc, char** argv) {
             r.renderBatch(have, static_cast<uint32_t>(spp));
             r.readSum(img);
             if (!checkpoint.empty()) {
-                FILE* f = std::fopen(checkpoint.c_str(), "wb");
-                if (!f) throw std::runtime_error("cannot write " + checkpoint);
-                std::fprintf(f, "MPTSUM1 %d %d %u %u %d %d\n", width, height, have + static_cast<uint32_t>(spp), seed, prm.rng_mode, depth);
+                const std::string tmp = checkpoint + ".tmp";
+                FILE* f = std::fopen(tmp.c_str(), "wb");
+                if (!f) throw std::runtime_error("cannot write " + tmp);
+                std::fprintf(f, "MPTSUM2 %d %d %u %u %d %d %d %llx\n", width, height, have + static_cast<uint32_t>(spp), seed, prm.rng_mode, depth, prm.bsdf_mode,
+                             sceneHash);
                 const bool ok = std::fwrite(img.data(), sizeof(float), img.size(), f) == img.size();
-                if (std::fclose(f) != 0 || !ok) throw std::runtime_error("cannot write " + checkpoint);
+                if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), checkpoint.c_str()) != 0) {
+                    std::remove(tmp.c_str());
+                    throw std::runtime_error("cannot write " + checkpoint);
+                }
             }
             scale = 1.0f / static_cast<float>(have + static_cast<uint32_t>(spp));
         }

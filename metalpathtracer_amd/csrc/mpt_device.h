@@ -34,9 +34,46 @@ __device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ F3 cross3(F3 a, F3 b) {
     return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+// ---- 1.0f / x ---------------------------------------------------------------------------------------
+// The compiler expands a correctly rounded FP32 division into v_div_scale x 2, v_rcp_f32, one multiply and five fused
+// multiply-adds, v_div_fmas and v_div_fixup: 11 vector instructions.  v_div_scale / v_div_fmas / v_div_fixup only do
+// something when an operand or the quotient leaves the normal range (or is 0 / Inf / NaN); everywhere else the result
+// is the fma chain alone — rcp_chain() below, 7 instructions, the SAME operations in the same order.  The range in
+// which the two agree bit for bit is not argued but MEASURED on the device over all 2^32 operands (k_kat_rcp,
+// tests/test_gpu_parity.py::test_reciprocal_chain_equals_ieee_division_on_all_operands): every x with
+// MPT_RCP_LO <= |x| <= MPT_RCP_HI.  mpt_rcp() takes the chain inside that range and the full expansion outside, under
+// a branch that whole waves skip.  MPT_FAST_RCP: 0 = always the full expansion (rounds 1-4), 1 = guarded chain,
+// 2 = unguarded chain (pricing experiment only: wrong for operands outside the range).
+#ifndef MPT_FAST_RCP
+#define MPT_FAST_RCP 0
+#endif
+#define MPT_RCP_LO 1.1754943508222875e-38f   // 2^-126 (smallest normal)
+#define MPT_RCP_HI 8.5070591730234616e+37f   // 2^126
+__device__ __forceinline__ float rcp_chain(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e0 = fmaf(-x, r, 1.0f);
+    r = fmaf(e0, r, r);
+    float q = r;                               // (1.0f * r)
+    const float e1 = fmaf(-x, q, 1.0f);
+    q = fmaf(e1, r, q);
+    const float e2 = fmaf(-x, q, 1.0f);
+    return fmaf(e2, r, q);
+}
+__device__ __forceinline__ bool rcp_chain_exact(float x) { return fabsf(x) >= MPT_RCP_LO && fabsf(x) <= MPT_RCP_HI; }
+__device__ __forceinline__ float mpt_rcp(float x) {
+#if MPT_FAST_RCP == 2
+    return rcp_chain(x);
+#elif MPT_FAST_RCP == 1
+    float r = rcp_chain(x);
+    if (__builtin_expect(!rcp_chain_exact(x), 0)) r = 1.0f / x;
+    return r;
+#else
+    return 1.0f / x;
+#endif
+}
 // normalize = v * (1 / sqrt(dot(v,v))) — same definition as the oracle (see its comment).
 __device__ __forceinline__ F3 normalize3(F3 a) {
-    float inv = 1.0f / sqrtf(dot3(a, a));
+    float inv = mpt_rcp(sqrtf(dot3(a, a)));
     return a * inv;
 }
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
@@ -177,6 +214,8 @@ struct WorkCount {
 #ifdef MPT_OT_TIMES
     unsigned long long ot_node_cycles, ot_leaf_cycles, ot_node_trips, ot_leaf_trips, ot_rounds;  // closest-first walk, per wave
     unsigned long long ot_node_lanes, ot_leaf_lanes;  // ... lanes that took part in those trips (per lane)
+    unsigned long long ot_lds_nodes, ot_glb_nodes, ot_lds_prims, ot_glb_prims;  // node visits / primitive records by where they were served from (per lane)
+    unsigned long long ot_pops, ot_pop_iters, ot_pop_calls, ot_pop_wave_iters;   // stack pops: calls and entries examined per lane; calls and loop trips per wave
 #endif
 };
 #ifdef MPT_DEBUG_WAVE_TIMES
@@ -258,7 +297,7 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
 #else
             if (fabsf(a) > 1e-5f) {
 #endif
-                float f = 1.0f / a;
+                float f = mpt_rcp(a);
                 F3 s = o - v0;
                 float u = f * dot3(s, h);
                 if (u >= 0.0f && u <= 1.0f) {
@@ -316,7 +355,7 @@ template <bool COUNT, bool ALL_LDS, bool BUDGETED>
 __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d, uint32_t& node,
                                                    float& best_t, int& best_prim, uint32_t budget, WorkCount& wc,
                                                    uint32_t min_active = 0u) {
-    const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;  // PathTracing.h:61 (per call there)
+    const float idx = mpt_rcp(d.x), idy = mpt_rcp(d.y), idz = mpt_rcp(d.z);  // PathTracing.h:61 (per call there): 1.0 / r.direction[i]
     const uint32_t n_nodes = sc.n_nodes, n_lds = sc.n_lds_nodes;
     // A direction with a NaN component (normalize of a zero vector: e.g. a refraction at the critical angle whose
     // discriminant rounds below zero) hits nothing — every sphere / triangle test mixes all three components and ends

@@ -15,6 +15,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <map>
 #include <memory>
@@ -89,8 +92,31 @@ struct Lane {
     bool timed = false;
 };
 
+// mpt_render_async's submit thread (one per context, started by the first asynchronous render).  What a submission may have to wait
+// for — the render lane it is going to use (two renders are in flight), the residency announcement of the trace kernel before it (the
+// gate of run_pass, up to 200 ms when a foreign kernel holds the chip) — it waits for HERE, not on the caller's thread: mpt_render_async
+// checks its arguments, queues the parameters and returns (round 4's version spun on the caller's thread: VERDICT r4 item 7).  The reference's
+// per-frame submit is unfenced in the same way (R/Renderer/Renderer.cpp:253-266,307: commit() and return).  Every other entry point of the
+// context first drains the queue (drain_submit), so the context stays single-threaded from the caller's point of view; the first
+// failure of a queued render is reported by the call that drains it (mpt_wait, or whatever comes next).
+struct Submitter {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<mpt_render_params> q;
+    bool busy = false, stop = false;
+    int rc = 0;            // first failure of a queued render since the last drain
+    std::string err;
+};
+#define MPT_ASYNC_QUEUE_MAX 64   // queued renders beyond this make mpt_render_async wait for room (back pressure, not an error)
+
 struct mpt_ctx {
     int device = 0;
+    std::unique_ptr<Submitter> sub;      // mpt_render_async's submit thread (none until the first asynchronous render)
+    uint64_t async_jobs = 0;             // renders submitted by that thread
+    uint64_t gate_resident = 0;          // residency gate: the trace kernel before was resident (or finished) when asked
+    uint64_t gate_timeout = 0;           // ... it was not within 200 ms: the event chain instead (a foreign kernel holds the chip)
+    uint64_t async_call_us_max = 0;      // longest mpt_render_async call so far, microseconds of host time
     hipStream_t stream = nullptr;   // == lane[0].stream: uploads, clears, read-backs, mpt_draw
     Lane lane[2];
     int next_lane = 0;
@@ -104,6 +130,7 @@ struct mpt_ctx {
     hipEvent_t ev_sum_op = nullptr;      // recorded behind mpt_clear_sum
     hipDeviceProp_t prop;
     std::string err;
+    std::mutex err_mu;                   // writers of `err`: the caller's thread and the submit thread (set_err)
     // scene
     float4* d_nodes = nullptr;
     float4* d_prims = nullptr;
@@ -191,20 +218,27 @@ static const void* wavelocal_kernel(bool count, bool all_lds, bool corun) {
 #define MPT_LDS_MATS MPT_LDS_MATS_N               // materials staged in LDS (32 B each; mpt_kernels.h)
 #define MPT_LDS_EXTRA (MPT_LDS_CFG_F4 * 16 + MPT_LDS_MATS * 32)  // material table + descriptor copy (k_step) / configuration block (k_wavelocal, k_ordered) behind the scene image
 
+static void set_err(mpt_ctx* ctx, const std::string& msg);   // ctx->err = msg under ctx->err_mu (the submit thread may fail at the same moment)
 #define HIPCHK(call)                                                                        \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \
         if (e_ != hipSuccess) {                                                             \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            set_err(ctx, std::string(#call) + ": " + hipGetErrorString(e_));                \
             return MPT_ERR_HIP;                                                             \
         }                                                                                   \
     } while (0)
 
+static void set_err(mpt_ctx* ctx, const std::string& msg) {
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    ctx->err = msg;
+}
 static int fail(mpt_ctx* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
+    if (ctx) set_err(ctx, msg);
     return code;
 }
 static int wait_impl(mpt_ctx* ctx);  // collects the renders still in flight (defined with the render entry points)
+static int drain_submit(mpt_ctx* ctx);   // waits until the renders queued by mpt_render_async have been submitted (struct Submitter)
+static void stop_submit(mpt_ctx* ctx);
 
 extern "C" const char* mpt_status_string(int s) {
     switch (s) {
@@ -248,7 +282,7 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
         if (hipMemset(L.d_ctr, 0, MPT_CTR_WORDS * 4) != hipSuccess) return bail(MPT_ERR_HIP);
         if (hipHostMalloc((void**)&L.h_done, 64, hipHostMallocMapped) != hipSuccess) return bail(MPT_ERR_HIP);
         if (hipHostMalloc((void**)&L.h_desc, sizeof(PassDesc), hipHostMallocDefault) != hipSuccess) return bail(MPT_ERR_HIP);
-        *L.h_done = 0;
+        memset((void*)L.h_done, 0, 64);   // (every word: the residency gate polls word MPT_HOST_RESIDENT against small launch ids — ADVICE r4)
         if (hipEventCreate(&L.ev0) != hipSuccess || hipEventCreate(&L.ev1) != hipSuccess ||
             hipEventCreate(&L.ev_resolved) != hipSuccess || hipEventCreateWithFlags(&L.ev_traced, hipEventDisableTiming) != hipSuccess)
             return bail(MPT_ERR_HIP);
@@ -350,6 +384,7 @@ static void free_queues(Lane& L) {
 
 extern "C" int mpt_destroy(mpt_ctx* ctx) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
+    stop_submit(ctx);   // (renders still queued are submitted, then the thread ends)
     hipSetDevice(ctx->device);
     for (Lane& L : ctx->lane)
         if (L.stream) hipStreamSynchronize(L.stream);
@@ -431,9 +466,9 @@ static void size_lds_images(mpt_ctx* ctx) {
         const size_t all_nodes = (size_t)ctx->n_acc_nodes * 112, all_prims = (size_t)ctx->n_prims * 48;
         size_t prim_bytes = all_nodes <= total ? std::min(all_prims, total - all_nodes)
                                                : std::min<size_t>(all_prims, std::min<size_t>(4 * 1024, total / 4));
+        if (const char* e = getenv("MPT_OT_LDS_PRIMS")) prim_bytes = std::min<size_t>(prim_bytes, (size_t)atoi(e) * 48);
         prim_bytes -= prim_bytes % 48;
         ctx->ot_lds_prims = (uint32_t)(prim_bytes / 48);
-        if (const char* e = getenv("MPT_OT_LDS_PRIMS")) ctx->ot_lds_prims = std::min<uint32_t>(ctx->ot_lds_prims, (uint32_t)atoi(e));
         ctx->ot_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
     }
 }
@@ -863,7 +898,9 @@ extern "C" int mpt_sum_buffer(mpt_ctx* ctx, void** p, uint64_t* bytes) {
 }
 extern "C" int mpt_set_sum_buffer(mpt_ctx* ctx, void* p) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
-    int wrc = wait_impl(ctx);
+    int wrc = drain_submit(ctx);
+    if (wrc) return wrc;
+    wrc = wait_impl(ctx);
     if (wrc) return wrc;
     ctx->d_sum = p ? (float4*)p : ctx->d_sum_own;
     return MPT_OK;
@@ -880,7 +917,10 @@ static int clear_sum_impl(mpt_ctx* ctx) {
 }
 extern "C" void* mpt_stream(mpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" int mpt_synchronize(mpt_ctx* ctx) {
-    int wrc = wait_impl(ctx);
+    if (!ctx) return MPT_ERR_INVALID_ARG;
+    int wrc = drain_submit(ctx);
+    if (wrc) return wrc;
+    wrc = wait_impl(ctx);
     if (wrc) return wrc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MPT_OK;
@@ -905,11 +945,13 @@ static int read_sum_impl(mpt_ctx* ctx, float* out) {
 }
 extern "C" int mpt_get_stats(mpt_ctx* ctx, mpt_stats* out) {
     if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+    drain_submit(ctx);   // (a failure of a queued render stays for the next call that can report it: this one returns numbers)
     *out = ctx->stats;
     return MPT_OK;
 }
 extern "C" int mpt_reset_stats(mpt_ctx* ctx) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
+    drain_submit(ctx);
     ctx->stats = mpt_stats{};
     return MPT_OK;
 }
@@ -948,13 +990,25 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     a.lds_always_off = 7u * a.n_lds_nodes;
     s.lds_prim_off = a.lds_always_off + 5u * a.n_always;
     s.lds_mat_off = s.lds_prim_off + 3u * s.n_lds_prims;
-    const uint32_t image4 = s.lds_mat_off + 2u * MPT_LDS_MATS + MPT_LDS_CFG_F4;   // (+ the kernel's configuration block behind the material table)
+    const uint32_t image4 = mpt_lds_image_end_f4(s.lds_mat_off);   // (material table + the kernel's configuration block: the one definition of mpt_kernels.h)
     a.lds_stack_off = image4 * 16u;
     a.stack_depth = stack_depth;
     a.eps_abs = ctx->acc_eps_abs;
     a.cull_rel = ctx->acc_cull_rel;
     a.o_limit = ctx->tri_extent > 0.0f ? 64.0f * ctx->tri_extent : INFINITY;  // no triangles: no tree, nothing to bound
     return (size_t)a.lds_stack_off + (size_t)threads * stack_depth * 8u;
+}
+// The regions of k_ordered's LDS image in the order the kernel addresses them: nodes, always list, primitives, materials, configuration
+// block, per-lane stacks.  None may overlap the next and the last must end inside the launch's allocation (the check that would have
+// caught round 4's fault at the first launch instead of on the GPU: see mpt_lds_cfg_off_f4).
+static bool ordered_layout_ok(const SceneDev& s, const AccelDev& a, uint32_t threads, size_t lds_bytes) {
+    const uint64_t nodes_end = 7ull * a.n_lds_nodes, always_end = (uint64_t)a.lds_always_off + 5ull * a.n_always,
+                   prims_end = (uint64_t)s.lds_prim_off + 3ull * s.n_lds_prims, mats_end = (uint64_t)s.lds_mat_off + 2ull * s.n_lds_mats,
+                   cfg_begin = mpt_lds_cfg_off_f4(s.lds_mat_off), cfg_end = mpt_lds_image_end_f4(s.lds_mat_off),
+                   stack_end = (uint64_t)a.lds_stack_off + (uint64_t)threads * a.stack_depth * 8u;
+    return nodes_end <= a.lds_always_off && always_end <= s.lds_prim_off && prims_end <= s.lds_mat_off && mats_end <= cfg_begin &&
+           cfg_end * 16u <= a.lds_stack_off && (a.lds_stack_off & 7u) == 0u && stack_end <= lds_bytes && a.stack_depth >= 2u && a.stack_depth <= MPT_OT_PARK &&
+           (uint64_t)a.n_nodes < (1ull << 24) /* MPT_OT_SIGNSEL: node offsets by a 24-bit multiply */;
 }
 // Fragment.metal:29 + Random.h:32-35: per-pixel u32 seed of the literal RNG.  The float sin-hash is
 // chaotic in the last ulp of sin(), so it is evaluated once on the host with the
@@ -1158,7 +1212,10 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     const int wg_max = pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : 1024;
     const int wg = pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : ctx->wg_size > 0 && ctx->wg_size <= wg_max ? ctx->wg_size : wg_max;
     AccelDev accel = {};
-    if (pipeline == MPT_PIPE_ORDERED) lds = ordered_views(ctx, (uint32_t)wg, ctx->ot_stack_depth, pp.scene, accel);
+    if (pipeline == MPT_PIPE_ORDERED) {
+        lds = ordered_views(ctx, (uint32_t)wg, ctx->ot_stack_depth, pp.scene, accel);
+        if (!ordered_layout_ok(pp.scene, accel, (uint32_t)wg, lds)) return fail(ctx, MPT_ERR_INVALID_ARG, "LDS layout of the closest-first kernel overlaps (internal)");
+    }
     if (ctx->occ_fun == kfun && ctx->occ_lds == lds) {
         per_cu = ctx->occ_per_cu;
     } else {
@@ -1198,6 +1255,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
                 std::this_thread::yield();
             }
+            (resident ? ctx->gate_resident : ctx->gate_timeout)++;
         }
         need_chain = !resident;
     }
@@ -1445,7 +1503,7 @@ static int render_async_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \
         if (e_ != hipSuccess) {                                                             \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            set_err(ctx, std::string(#call) + ": " + hipGetErrorString(e_));                \
             return abandon(MPT_ERR_HIP);                                                    \
         }                                                                                   \
     } while (0)
@@ -1480,6 +1538,18 @@ static int render_async_impl(mpt_ctx* ctx, const mpt_render_params* p) {
 #undef HIPCHK_AB
 }
 
+// "Nothing else is in flight and nothing will be submitted behind this render": the trace kernel may be the variant that fills the
+// scalar register file and the resolve may take the whole chip.  Set for the duration of mpt_render / mpt_draw; a guard, so that no
+// exit path (an exception turned into a status by guarded()) leaves it set.
+namespace {
+struct SyncRenderScope {
+    mpt_ctx* ctx;
+    explicit SyncRenderScope(mpt_ctx* c) : ctx(c) { ctx->sync_render = true; }
+    ~SyncRenderScope() { ctx->sync_render = false; }
+    SyncRenderScope(const SyncRenderScope&) = delete;
+    SyncRenderScope& operator=(const SyncRenderScope&) = delete;
+};
+}  // namespace
 static int render_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     int rc = wait_impl(ctx);
     if (rc) return rc;
@@ -1487,9 +1557,10 @@ static int render_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     ctx->stats.trace_launches = 0;
     ctx->stats.total_ms = 0;
     ctx->next_lane = 0;  // nothing is in flight: serial renders stay on lane 0 (the second lane allocates only if used)
-    ctx->sync_render = true;
-    rc = render_async_impl(ctx, p);
-    ctx->sync_render = false;
+    {
+        SyncRenderScope sync(ctx);
+        rc = render_async_impl(ctx, p);
+    }
     if (rc) return rc;
     return wait_impl(ctx);
 }
@@ -1498,6 +1569,7 @@ static int draw_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     int rc = check_ready(ctx, p);
     if (rc) return rc;
     if ((rc = wait_impl(ctx))) return rc;
+    SyncRenderScope sync(ctx);   // (the frame protocol is synchronous: one frame at a time, collected before the call returns)
     Lane& L = ctx->lane[0];
     ctx->cur_target ^= 1;  // std::swap(_accumulationTargets[0], [1]) — Renderer.cpp:278
     PassParams pp;
@@ -1575,6 +1647,7 @@ static int trace_rays_ordered_impl(mpt_ctx* ctx, const float* o, const float* d,
     SceneDev sc;
     AccelDev ac;
     const size_t lds = ordered_views(ctx, 256, ctx->ot_stack_depth, sc, ac);
+    if (!ordered_layout_ok(sc, ac, 256u, lds)) return fail(ctx, MPT_ERR_INVALID_ARG, "LDS layout of the closest-first kernel overlaps (internal)");
     hipLaunchKernelGGL(k_trace_rays_ordered, dim3(blocks), dim3(256), lds, ctx->stream, sc, ac, (const float*)d_o.p, (const float*)d_d.p,
                        (uint32_t)n, (float*)d_t.p, (int*)d_p.p, (float*)d_n.p, (int*)d_f.p, (uint32_t*)d_g.p);
     HIPCHK(hipGetLastError());
@@ -1642,7 +1715,18 @@ static int kat_sincos_impl(mpt_ctx* ctx, const float* u, uint64_t n, float* s, f
                            (const float*)di[0], (uint32_t)n, (float*)dout[0], (float*)dout[1]);
     });
 }
-
+static int kat_rcp_impl(mpt_ctx* ctx, uint64_t* out4) {
+    if (!ctx || !out4) return MPT_ERR_INVALID_ARG;
+    const uint64_t zero[4] = {0, 0, 0, 0};
+    const void* in[] = {zero};
+    size_t ib[] = {sizeof zero};
+    void* out[] = {out4};
+    size_t ob[] = {sizeof zero};
+    return kat_run(ctx, in, ib, 1, out, ob, 1, [&](std::vector<void*>& di, std::vector<void*>& dout) {
+        (void)hipMemcpyAsync(dout[0], di[0], sizeof zero, hipMemcpyDeviceToDevice, ctx->stream);   // (an error shows in hipGetLastError of kat_run)
+        hipLaunchKernelGGL(k_kat_rcp, dim3(65536), dim3(256), 0, ctx->stream, (unsigned long long*)dout[0]);
+    });
+}
 
 // The binary tree of the GPU builders (mpt_lbvh.h).  Default: top-down binned SAH over the primitives (as good a tree as the host's
 // binned builder).  MPT_GPU_BUILD = ploc: the clustering pass (25 % faster to build, renders 1-7 % slower); lbvh: the plain Karras tree.
@@ -1758,15 +1842,98 @@ static int download_bvh_impl(mpt_ctx* ctx, float* bvh_out, uint64_t cap_nodes, u
     return MPT_OK;
 }
 
+// ---- mpt_render_async's submit thread (struct Submitter) -------------------------------------------------------------------------
+static void submit_thread_main(mpt_ctx* ctx) {
+    Submitter& S = *ctx->sub;
+    std::unique_lock<std::mutex> lk(S.mu);
+    for (;;) {
+        S.cv_work.wait(lk, [&] { return S.stop || !S.q.empty(); });
+        if (S.q.empty()) return;   // (stop, and nothing left to submit)
+        const mpt_render_params p = S.q.front();
+        S.q.pop_front();
+        S.busy = true;
+        lk.unlock();
+        int rc = MPT_ERR_HIP;
+        try {
+            rc = render_async_impl(ctx, &p);
+            ctx->async_jobs++;
+        } catch (const std::exception& e) {
+            try {
+                set_err(ctx, std::string("host exception: ") + e.what());
+            } catch (...) {
+            }
+        } catch (...) {
+        }
+        lk.lock();
+        if (rc != MPT_OK && S.rc == MPT_OK) {
+            S.rc = rc;
+            S.err = ctx->err;
+        }
+        S.busy = false;
+        S.cv_idle.notify_all();
+    }
+}
+// Everything queued has been submitted (and the thread is idle): the context is the caller's alone again.  Returns the first failure of
+// a queued render, once.  Called by every entry point except mpt_render_async.
+static int drain_submit(mpt_ctx* ctx) {
+    if (!ctx || !ctx->sub) return MPT_OK;
+    Submitter& S = *ctx->sub;
+    if (std::this_thread::get_id() == S.th.get_id()) return MPT_OK;   // (the submit thread itself, inside render_async_impl)
+    std::unique_lock<std::mutex> lk(S.mu);
+    S.cv_idle.wait(lk, [&] { return S.q.empty() && !S.busy; });
+    const int rc = S.rc;
+    if (rc != MPT_OK) {
+        set_err(ctx, S.err);
+        S.rc = MPT_OK;
+        S.err.clear();
+    }
+    return rc;
+}
+static void stop_submit(mpt_ctx* ctx) {
+    if (!ctx || !ctx->sub) return;
+    {
+        std::lock_guard<std::mutex> lk(ctx->sub->mu);
+        ctx->sub->stop = true;
+    }
+    ctx->sub->cv_work.notify_all();
+    if (ctx->sub->th.joinable()) ctx->sub->th.join();   // (queued renders are submitted first: the thread leaves on an empty queue)
+    ctx->sub.reset();
+}
+static int enqueue_render(mpt_ctx* ctx, const mpt_render_params* p) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = check_ready(ctx, p);   // argument and state errors are the caller's, at once (the state they depend on only changes in calls that drain)
+    if (rc) return rc;
+    if (!ctx->sub) {
+        ctx->sub.reset(new Submitter());
+        ctx->sub->th = std::thread(submit_thread_main, ctx);
+    }
+    Submitter& S = *ctx->sub;
+    {
+        std::unique_lock<std::mutex> lk(S.mu);
+        S.cv_idle.wait(lk, [&] { return S.q.size() < MPT_ASYNC_QUEUE_MAX; });
+        S.q.push_back(*p);
+    }
+    S.cv_work.notify_one();
+    const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    ctx->async_call_us_max = std::max(ctx->async_call_us_max, us);
+    return MPT_OK;
+}
+
 // ---- exception barrier: nothing thrown by the host-side containers may cross the C ABI (include/mpt.h) --------
-template <class F>
+// (and the join point of the submit thread: every guarded entry point first waits until the renders queued by mpt_render_async have
+//  been submitted — DRAIN = false for mpt_render_async itself)
+template <bool DRAIN = true, class F>
 static int guarded(mpt_ctx* ctx, F&& body) noexcept {
     try {
+        if (DRAIN) {
+            const int d = drain_submit(ctx);
+            if (d) return d;
+        }
         return body();
     } catch (const std::exception& e) {
         if (ctx) {
             try {
-                ctx->err = std::string("host exception: ") + e.what();
+                set_err(ctx, std::string("host exception: ") + e.what());
             } catch (...) {
             }
         }
@@ -1825,7 +1992,15 @@ extern "C" int mpt_render(mpt_ctx* ctx, const mpt_render_params* p) {
     return guarded(ctx, [&] { return render_impl(ctx, p); });
 }
 extern "C" int mpt_render_async(mpt_ctx* ctx, const mpt_render_params* p) {
-    return guarded(ctx, [&] { return render_async_impl(ctx, p); });
+    return guarded<false>(ctx, [&] { return enqueue_render(ctx, p); });
+}
+extern "C" int mpt_async_info(mpt_ctx* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        const uint64_t v[4] = {ctx->async_jobs, ctx->gate_resident, ctx->gate_timeout, ctx->async_call_us_max};
+        memcpy(out, v, sizeof v);
+        return (int)MPT_OK;
+    });
 }
 extern "C" int mpt_wait(mpt_ctx* ctx) {
     return guarded(ctx, [&] { return wait_impl(ctx); });
@@ -1898,6 +2073,10 @@ extern "C" int mpt_kat_philox(mpt_ctx* ctx, const uint32_t* c, const uint32_t* k
 
 extern "C" int mpt_kat_sincos(mpt_ctx* ctx, const float* u, uint64_t n, float* s, float* c) {
     return guarded(ctx, [&] { return kat_sincos_impl(ctx, u, n, s, c); });
+}
+
+extern "C" int mpt_kat_rcp(mpt_ctx* ctx, uint64_t* out4) {
+    return guarded(ctx, [&] { return kat_rcp_impl(ctx, out4); });
 }
 
 // ---- multi-GPU: RCCL reduce of the HDR sum (include/mpt.h) ----------------------------------------------------------
@@ -2036,7 +2215,8 @@ extern "C" int mpt_reduce_sum(mpt_comm* c, int root) {
     // every local context: collect the renders in flight (their resolves have then updated the HDR sum)
     int local_rc = MPT_OK;
     for (mpt_ctx* ctx : c->ctxs) {
-        int rc = wait_impl(ctx);
+        int rc = drain_submit(ctx);
+        if (!rc) rc = wait_impl(ctx);
         if (rc) {
             c->err = ctx->err;
             local_rc = rc;
@@ -2088,13 +2268,13 @@ extern "C" int mpt_comm_destroy(mpt_comm* c) {
 }
 
 #ifdef MPT_OT_TIMES
-extern "C" int mpt_debug_ot_times(unsigned long long* out32, int reset) {   // [0,24) g_ot_times, [24,32) g_ot_walk
-    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_ot_times), 24 * 8);
-    if (e == hipSuccess) e = hipMemcpyFromSymbol(out32 + 24, HIP_SYMBOL(g_ot_walk), 8 * 8);
+extern "C" int mpt_debug_ot_times(unsigned long long* out40, int reset) {   // [0,24) g_ot_times, [24,40) g_ot_walk
+    hipError_t e = hipMemcpyFromSymbol(out40, HIP_SYMBOL(g_ot_times), 24 * 8);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out40 + 24, HIP_SYMBOL(g_ot_walk), 16 * 8);
     if (e == hipSuccess && reset) {
         unsigned long long z[24] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_ot_times), z, sizeof z);
-        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ot_walk), z, 8 * 8);
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ot_walk), z, 16 * 8);
     }
     return (int)e;
 }

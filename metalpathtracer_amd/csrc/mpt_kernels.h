@@ -526,6 +526,14 @@ __device__ __forceinline__ uint32_t wave_rank(unsigned long long m) {
 #define MPT_LDS_MATS_N 32u     // materials staged in LDS (= MPT_LDS_MATS of mpt_hip.hip): the configuration block of k_wavelocal / k_ordered starts behind them
 #define MPT_LDS_CFG_F4 16u     // ... and is this many float4 long (256 bytes): camera in float4 0..3, then 32 words (budgets 0..15, claim parameters 16..19).
                                // The host reserves it (MPT_LDS_EXTRA, ordered_views): k_ordered's stacks start right behind it.
+// Where the configuration block starts in a workgroup's LDS (float4 index), for the kernels AND for the host code that lays the
+// image out and sizes the launch (mpt_hip.hip: MPT_LDS_EXTRA, ordered_views) — one definition.  Round 4's development build of
+// k_ordered had two: the kernel wrote the block at lds_mat_off + 2 * MPT_LDS_MATS_N while ordered_views still put the per-lane stacks at
+// lds_mat_off + 2 * n_lds_mats, i.e. INSIDE the block's 256 bytes for any scene with fewer than 32 materials: stack pushes overwrote
+// the claim parameters and budgets, the block's words were popped as child references, and the walk fetched nodes far outside the
+// tree — the GPU memory fault behind the four aborted renders and the aborted test of gpurun_out/r04/s11_*.log (docs/HISTORY.md).
+__host__ __device__ __forceinline__ uint32_t mpt_lds_cfg_off_f4(uint32_t lds_mat_off) { return lds_mat_off + 2u * MPT_LDS_MATS_N; }
+__host__ __device__ __forceinline__ uint32_t mpt_lds_image_end_f4(uint32_t lds_mat_off) { return mpt_lds_cfg_off_f4(lds_mat_off) + MPT_LDS_CFG_F4; }
 #define MPT_WL_BLOCK 1024u     // upper bound of a path-id claim
 #define MPT_WL_NO_BUDGET 0x7FFFFFFFu  // budgets at or above this mean "run to completion"
 // Ring record (round 4, "the traffic diet"): 48 bytes that every ray needs — od, dt, ia — and 16 more (tl: the light gathered so
@@ -686,7 +694,7 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
     // what only some steps need goes to LDS, behind the scene image (the 256-byte descriptor area of MPT_LDS_EXTRA), instead of
     // living in scalar registers across the whole step loop: the camera (14 words, primary steps) and the ring budgets (10 words,
     // ring steps).  The loop needs more scalar registers than the 102 a wave has; every value kept out of it is one spill less.
-    const uint32_t cfg_off = pp.scene.lds_mat_off + 2u * MPT_LDS_MATS_N;   // in float4 units
+    const uint32_t cfg_off = mpt_lds_cfg_off_f4(pp.scene.lds_mat_off);   // in float4 units
     if (threadIdx.x == 0) {
         announce_resident(pp);
         lds_nodes_raw[cfg_off + 0] = make_float4(pp.cam.x, pp.cam.y, pp.cam.z, pp.W);
@@ -1147,6 +1155,37 @@ __global__ void k_kat_philox(const uint32_t* c, const uint32_t* k, uint32_t n, u
         o[4 * i + 1] = r.y;
         o[4 * i + 2] = r.z;
         o[4 * i + 3] = r.w;
+    }
+}
+// All 2^32 operands: rcp_chain(x) against the compiler's correctly rounded 1.0f / x, bit for bit (mpt_device.h, mpt_rcp).
+// out = {mismatches with |x| in [MPT_RCP_LO, MPT_RCP_HI], operands in that range, mismatches outside it, operands outside it}
+__global__ void k_kat_rcp(unsigned long long* out) {
+    unsigned long long bad_in = 0, n_in = 0, bad_out = 0, n_out = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;   // a power of two that divides 2^32 (the host launches 65536 x 256)
+    uint32_t bits = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t it = 0; it < (uint32_t)(0x100000000ull / stride); ++it, bits += stride) {
+        const float x = __uint_as_float(bits);
+        const uint32_t a = __float_as_uint(rcp_chain(x)), b = __float_as_uint(1.0f / x);
+        const bool same = a == b || ((a & 0x7FFFFFFFu) > 0x7F800000u && (b & 0x7FFFFFFFu) > 0x7F800000u);   // (two NaNs are the same answer)
+        if (rcp_chain_exact(x)) {
+            n_in++;
+            bad_in += same ? 0u : 1u;
+        } else {
+            n_out++;
+            bad_out += same ? 0u : 1u;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad_in += __shfl_down(bad_in, off);
+        n_in += __shfl_down(n_in, off);
+        bad_out += __shfl_down(bad_out, off);
+        n_out += __shfl_down(n_out, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (bad_in) atomicAdd(out + 0, bad_in);
+        atomicAdd(out + 1, n_in);
+        if (bad_out) atomicAdd(out + 2, bad_out);
+        atomicAdd(out + 3, n_out);
     }
 }
 __global__ void k_kat_sincos(const float* u, uint32_t n, float* s, float* c) {

@@ -97,7 +97,9 @@
 // lane counts per step kind (tools/gpu_ot_times.py).  Not compiled into the product library.
 #ifdef MPT_OT_TIMES
 #define OT_NREG 8   // select, fetch, top test, walk, final check, exact walk, shade, push
-__device__ unsigned long long g_ot_walk[8];     // closest-first walk: node-loop cycles, leaf-loop cycles, node trips, leaf trips, rounds, node lane-trips, leaf lane-trips
+__device__ unsigned long long g_ot_walk[16];    // closest-first walk: node-loop cycles, leaf-loop cycles, node trips, leaf trips, rounds, node lane-trips, leaf lane-trips,
+                                                // [7..10] node visits served from LDS / from global memory, primitive records loaded from LDS / from global memory (per lane),
+                                                // [11..14] stack pops: calls (lanes), entries examined (lanes), calls (waves), loop trips (waves)
 __device__ unsigned long long g_ot_times[OT_NREG + 16];   // + steps[RINGS + 1] at 8, lanes[RINGS + 1] at 16
 #define OT_TIC() unsigned long long ot_t_ = __builtin_amdgcn_s_memtime()
 #define OT_TOC(r)                                                   \
@@ -107,8 +109,9 @@ __device__ unsigned long long g_ot_times[OT_NREG + 16];   // + steps[RINGS + 1] 
         ot_t_ = now_;                                               \
     } while (0)
 __device__ __forceinline__ void ot_flush_walk_times(const WorkCount& wc, uint32_t lane) {
-    unsigned long long v[7] = {wc.ot_node_cycles, wc.ot_leaf_cycles, wc.ot_node_trips, wc.ot_leaf_trips, wc.ot_rounds, wc.ot_node_lanes, wc.ot_leaf_lanes};
-    for (int k = 0; k < 7; ++k) {
+    unsigned long long v[15] = {wc.ot_node_cycles, wc.ot_leaf_cycles, wc.ot_node_trips, wc.ot_leaf_trips, wc.ot_rounds, wc.ot_node_lanes, wc.ot_leaf_lanes,
+                                wc.ot_lds_nodes, wc.ot_glb_nodes, wc.ot_lds_prims, wc.ot_glb_prims, wc.ot_pops, wc.ot_pop_iters, wc.ot_pop_calls, wc.ot_pop_wave_iters};
+    for (int k = 0; k < 15; ++k) {
         if (k < 2 || k == 4) v[k] = __shfl(v[k], 0);   // cycles / rounds are per wave: lane 0's copy
         else for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
         if (lane == 0) atomicAdd(&g_ot_walk[k], v[k]);
@@ -185,8 +188,20 @@ struct OtStack {
 // farthest first, so that the nearest is popped first; with `room` free entries only the nearest `room` of them go in.
 __device__ __forceinline__ void ot_push_sorted(const OtStack& st, uint32_t& sp, const uint4& ref, uint32_t k1, uint32_t k2,
                                                uint32_t k3, bool& lost);
+// Near / far planes by ADDRESS (round 5, MPT_OT_SIGNSEL): a node stores lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4]; which of a slab's
+// two planes the ray meets first is the sign of 1/d — per ray, not per node.  Instead of computing both distances and taking
+// min / max (3 + 3 instructions per child box), a lane whose direction is negative on an axis swaps the two LOAD ADDRESSES of that axis
+// (a byte offset of 0 or 48 added to the node's address: 6 additions per node), and the distances come out as near / far:
+// t_near = max3, t_far = min3.  fma(b, 1/d, -o/d) is monotone in b and lo <= hi, so near = min(t_lo, t_hi) and far = max(...) EXACTLY:
+// the keys, and with them the walk, are bit for bit what they were (24 vector instructions less per node visit).
+#ifndef MPT_OT_SIGNSEL
+#define MPT_OT_SIGNSEL 1
+#endif
 struct OtRay {
     float idx, idy, idz, ox, oy, oz;  // approximate 1/d and o/d: own boxes are padded for it (mpt_hip.hip)
+#if MPT_OT_SIGNSEL
+    uint32_t sx, sy, sz;              // 48 where the direction is negative (the hi plane is the near one), else 0: byte offsets into a node
+#endif
 };
 __device__ __forceinline__ OtRay ot_ray(F3 o, F3 d) {
     OtRay r;
@@ -196,6 +211,11 @@ __device__ __forceinline__ OtRay ot_ray(F3 o, F3 d) {
     r.ox = o.x * r.idx;
     r.oy = o.y * r.idy;
     r.oz = o.z * r.idz;
+#if MPT_OT_SIGNSEL
+    r.sx = r.idx < 0.0f ? 48u : 0u;
+    r.sy = r.idy < 0.0f ? 48u : 0u;
+    r.sz = r.idz < 0.0f ? 48u : 0u;
+#endif
     return r;
 }
 // rays the closest-first walk does not take: a direction component that is (nearly) zero, or anything not finite
@@ -206,11 +226,75 @@ __device__ __forceinline__ bool ot_degenerate(F3 o, F3 d, float o_limit) {
 }
 
 struct OtNode {
-    float4 lx, ly, lz, hx, hy, hz;
+    float4 lx, ly, lz, hx, hy, hz;   // MPT_OT_SIGNSEL: l* = the planes the ray meets first, h* = the ones it leaves through
     uint4 ref;
 };
+#if MPT_OT_SIGNSEL
+typedef const __attribute__((address_space(3))) char* LdsBytes;
 template <bool ALL_LDS>
-__device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds, uint32_t n) {
+__device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds, uint32_t n, const OtRay& r) {
+    static_assert(MPT_OT_NODE_STRIDE == 7u && !MPT_OT_QNODES, "MPT_OT_SIGNSEL addresses the 112-byte float node");
+    OtNode nd;
+    const uint32_t at = __umul24(n, 112u);   // (n < 2^24: checked where the launch is sized, ordered_layout_ok)
+    // near planes at `at + s`, far planes at `(at + 48) - s`, the axis in the instruction's immediate offset (0 / 16 / 32): three
+    // registers per ray (sx, sy, sz), seven additions per node.  MPT_OT_SIGNSEL=2: six per-ray offsets, six additions (more registers).
+    v4f a, b, c, d, e, f, g;
+#if MPT_OT_SIGNSEL == 2
+    const uint32_t fx = 48u - r.sx, fy = 64u - r.sy, fz = 80u - r.sz, ny = 16u + r.sy, nz = 32u + r.sz;
+    if (ALL_LDS || n < ac.n_lds_nodes) {
+        const LdsBytes q = (LdsBytes)lds + at;
+        a = *(LdsNodes)(q + r.sx);
+        b = *(LdsNodes)(q + ny);
+        c = *(LdsNodes)(q + nz);
+        d = *(LdsNodes)(q + fx);
+        e = *(LdsNodes)(q + fy);
+        f = *(LdsNodes)(q + fz);
+        g = *(LdsNodes)(q + 96u);
+    } else {
+        const char* q = (const char*)ac.nodes;   // (32-bit offsets from the uniform base: global_load ... v_off, s[base:base+1])
+        a = *(const v4f*)(q + (at + r.sx));
+        b = *(const v4f*)(q + (at + ny));
+        c = *(const v4f*)(q + (at + nz));
+        d = *(const v4f*)(q + (at + fx));
+        e = *(const v4f*)(q + (at + fy));
+        f = *(const v4f*)(q + (at + fz));
+        g = *(const v4f*)(q + (at + 96u));
+    }
+#else
+    uint32_t at48 = at + 48u;
+    asm volatile("" : "+v"(at48));   // (kept as one value: the compiler would otherwise fold the 48 into six per-ray constants and hold six registers)
+    if (ALL_LDS || n < ac.n_lds_nodes) {
+        const LdsBytes qn = (LdsBytes)lds + at, qf = (LdsBytes)lds + at48;
+        a = *(LdsNodes)(qn + r.sx);
+        b = *(LdsNodes)(qn + r.sy + 16u);
+        c = *(LdsNodes)(qn + r.sz + 32u);
+        d = *(LdsNodes)(qf - r.sx);
+        e = *(LdsNodes)(qf - r.sy + 16u);
+        f = *(LdsNodes)(qf - r.sz + 32u);
+        g = *(LdsNodes)(qn + 96u);
+    } else {
+        const char* q = (const char*)ac.nodes;   // (32-bit offsets from the uniform base: global_load ... v_off, s[base:base+1] offset:imm)
+        a = *(const v4f*)(q + (at + r.sx));
+        b = *(const v4f*)(q + (at + r.sy) + 16);
+        c = *(const v4f*)(q + (at + r.sz) + 32);
+        d = *(const v4f*)(q + (at48 - r.sx));
+        e = *(const v4f*)(q + (at48 - r.sy) + 16);
+        f = *(const v4f*)(q + (at48 - r.sz) + 32);
+        g = *(const v4f*)(q + at + 96);
+    }
+#endif
+    nd.lx = make_float4(a.x, a.y, a.z, a.w);
+    nd.ly = make_float4(b.x, b.y, b.z, b.w);
+    nd.lz = make_float4(c.x, c.y, c.z, c.w);
+    nd.hx = make_float4(d.x, d.y, d.z, d.w);
+    nd.hy = make_float4(e.x, e.y, e.z, e.w);
+    nd.hz = make_float4(f.x, f.y, f.z, f.w);
+    nd.ref = make_uint4(__float_as_uint(g.x), __float_as_uint(g.y), __float_as_uint(g.z), __float_as_uint(g.w));
+    return nd;
+}
+#else
+template <bool ALL_LDS>
+__device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds, uint32_t n, const OtRay&) {
     OtNode nd;
     if (ALL_LDS || n < ac.n_lds_nodes) {
         const LdsNodes q = lds + 7u * n;
@@ -281,10 +365,15 @@ __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds,
 #endif
     return nd;
 }
+#endif
 // entry distance of the ray into one child box as a sort key: float bits with the child slot in the two low bits
 // (t >= 0, so unsigned order = float order; the key rounds the distance DOWN by at most 3 ulp), or KEY_MISS
 __device__ __forceinline__ uint32_t ot_box_key(const OtRay& r, float lx, float ly, float lz, float hx, float hy, float hz,
                                                uint32_t ref, float lim, uint32_t slot) {
+#if MPT_OT_SIGNSEL   // (lx .. lz are the near planes, hx .. hz the far ones: ot_load_node)
+    const float tn = fmaxf(fmaxf(fmaf(lx, r.idx, -r.ox), fmaf(ly, r.idy, -r.oy)), fmaxf(fmaf(lz, r.idz, -r.oz), 0.0f));
+    const float tf = fminf(fminf(fmaf(hx, r.idx, -r.ox), fmaf(hy, r.idy, -r.oy)), fmaf(hz, r.idz, -r.oz));
+#else
     float t0 = fmaf(lx, r.idx, -r.ox), t1 = fmaf(hx, r.idx, -r.ox);
     float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
     t0 = fmaf(ly, r.idy, -r.oy);
@@ -295,6 +384,7 @@ __device__ __forceinline__ uint32_t ot_box_key(const OtRay& r, float lx, float l
     t1 = fmaf(hz, r.idz, -r.oz);
     tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f);
     tf = fminf(tf, fmaxf(t0, t1));
+#endif
     // one comparison: tn <= tf * (1 + 2^-21) and tn <= lim (no NaN here: planes and 1/d are finite for the rays the walk
     // takes, or +inf for the x planes of an empty slot, which no ray enters — mpt_accel.h emit)
     (void)ref;
@@ -323,7 +413,7 @@ __device__ __forceinline__ void ot_test_prim(const Prim3& pr, uint32_t index, F3
         const F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
         const F3 h = cross3(d, e2);
         const float a = dot3(e1, h);
-        const float f = 1.0f / a;
+        const float f = mpt_rcp(a);
         const F3 s = o - v0;
         const float u = f * dot3(s, h);
         const F3 q = cross3(s, e1);
@@ -376,7 +466,7 @@ __device__ __forceinline__ void ot_top_test(const AccelDev& ac, LdsNodes lds, F3
         if (COUNT) wc.prim_tests++;
         ot_test_prim(pr, __float_as_uint(b.y), o, d, T, W, tie);
     }
-    const OtNode nd = ot_load_node<true>(ac, lds, 0u);   // the root is always staged
+    const OtNode nd = ot_load_node<true>(ac, lds, 0u, r);   // the root is always staged
     const float lim = ot_cull_limit(T, ac);
     const uint32_t k0 = ot_box_key(r, nd.lx.x, nd.ly.x, nd.lz.x, nd.hx.x, nd.hy.x, nd.hz.x, nd.ref.x, lim, 0u);
     const uint32_t k1 = ot_box_key(r, nd.lx.y, nd.ly.y, nd.lz.y, nd.hx.y, nd.hy.y, nd.hz.y, nd.ref.y, lim, 1u);
@@ -405,12 +495,21 @@ __device__ __forceinline__ void ot_push_sorted(const OtStack& st, uint32_t& sp, 
     if (h1 && room >= 1u) st.lds[sp++ * 64u] = v2u{k1, ot_pick(ref, k1)};
     lost = lost || (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3 > room;
 }
-__device__ __forceinline__ uint32_t ot_pop_next(const OtStack& st, uint32_t& sp, float lim) {
+__device__ __forceinline__ uint32_t ot_pop_next(const OtStack& st, uint32_t& sp, float lim, WorkCount& wc) {
+#ifdef MPT_OT_TIMES
+    wc.ot_pops++;
+    if (first_active_lane()) wc.ot_pop_calls++;
+#endif
     while (sp > 0u) {
         --sp;
         const v2u e = st.lds[sp * 64u];
+#ifdef MPT_OT_TIMES
+        wc.ot_pop_iters++;
+        if (first_active_lane()) wc.ot_pop_wave_iters++;
+#endif
         if (__uint_as_float(e.x & ~3u) <= lim) return e.y;
     }
+    (void)wc;
     return MPT_OT_DONE;
 }
 // Resumable: (cur, sp) and the lane's stack are the walk's state.  BUDGETED: the step ends when the wave has made
@@ -455,7 +554,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             if (!(cur < MPT_OT_LEAF)) continue;
             // (taking ONE source per trip for the whole wave — LDS only when every searching lane is at a staged node —
             // instead of a per-lane choice was measured on bunny x20: no difference, 20.7 ms either way)
-            const OtNode nd = ot_load_node<ALL_LDS>(ac, lds, cur);
+            const OtNode nd = ot_load_node<ALL_LDS>(ac, lds, cur, r);
             const float lim = ot_cull_limit(T, ac);
             uint32_t k0 = ot_box_key(r, nd.lx.x, nd.ly.x, nd.lz.x, nd.hx.x, nd.hy.x, nd.hz.x, nd.ref.x, lim, 0u);
             uint32_t k1 = ot_box_key(r, nd.lx.y, nd.ly.y, nd.lz.y, nd.hx.y, nd.hy.y, nd.hz.y, nd.ref.y, lim, 1u);
@@ -469,6 +568,8 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
 #ifdef MPT_OT_TIMES
             if (first_active_lane()) wc.ot_node_trips++;
             wc.ot_node_lanes++;
+            if (ALL_LDS || cur < ac.n_lds_nodes) wc.ot_lds_nodes++;
+            else wc.ot_glb_nodes++;
 #endif
             ot_sort2(k0, k1);
             ot_sort2(k2, k3);
@@ -479,7 +580,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                 cur = ot_pick(nd.ref, k0);
                 if (k1 < MPT_OT_KEY_MISS) ot_push_sorted(st, sp, nd.ref, k1, k2, k3, overflow);
             } else {
-                cur = ot_pop_next(st, sp, lim);
+                cur = ot_pop_next(st, sp, lim, wc);
             }
 #ifdef MPT_OT_TOUCH   // (experiment) a lane that has just found its leaf touches the leaf's first primitive: the line is on its way while the others search
             if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF && (cur & 0x07FFFFFFu) >= sc.n_lds_prims) touch = sc.prims[3u * (size_t)(cur & 0x07FFFFFFu)].x;
@@ -501,6 +602,12 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
 #ifdef MPT_OT_TIMES
                 if (first_active_lane()) wc.ot_leaf_trips++;
                 wc.ot_leaf_lanes++;
+                if (first < sc.n_lds_prims) wc.ot_lds_prims++;
+                else wc.ot_glb_prims++;
+                if (two) {
+                    if (first + 1u < sc.n_lds_prims) wc.ot_lds_prims++;
+                    else wc.ot_glb_prims++;
+                }
 #endif
                 if (COUNT && first_active_lane()) wc.prim_iters++;
                 if (!(ac.n_always != 0u && prim_type(pa.p0) == 0)) {
@@ -535,12 +642,14 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
 #ifdef MPT_OT_TIMES
                 if (first_active_lane()) wc.ot_leaf_trips++;
                 wc.ot_leaf_lanes++;
+                if (first + k < sc.n_lds_prims) wc.ot_lds_prims++;
+                else wc.ot_glb_prims++;
 #endif
                 if (ac.n_always != 0u && prim_type(pr.p0) == 0) continue;  // spheres are on the always list
                 if (COUNT) wc.prim_tests++;
                 ot_test_prim(pr, first + k, o, d, T, W, tie);
             }
-            cur = ot_pop_next(st, sp, ot_cull_limit(T, ac));
+            cur = ot_pop_next(st, sp, ot_cull_limit(T, ac), wc);
         }
         OT_WTOC(ot_leaf_cycles);
 #ifdef MPT_OT_TOUCH
@@ -595,7 +704,7 @@ __device__ __forceinline__ bool ot_final_check(const AccelDev& ac, const SceneDe
         const float err = (m + fmaxf(fabsf(r.ox), fmaxf(fabsf(r.oy), fabsf(r.oz)))) * 9.5367431640625e-07f;
         if (hi - err > lo + err && T >= lo + err) return true;  // (a NaN anywhere fails this and takes the exact test)
     }
-    const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;
+    const float idx = mpt_rcp(d.x), idy = mpt_rcp(d.y), idz = mpt_rcp(d.z);
     float t0 = (n0.x - o.x) * idx, t1 = (n1.x - o.x) * idx;
     float lo = fmaxf(0.0001f, idx < 0.0f ? t1 : t0);
     float hi = idx < 0.0f ? t0 : t1;
@@ -763,7 +872,7 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
     extern __shared__ float4 lds_raw[];
     // camera and budgets live in LDS (the MPT_LDS_CFG_F4 block behind the material table), not in scalar registers across the step loop
     // (as in k_wavelocal, mpt_kernels.h)
-    const uint32_t cfg_off = pp.scene.lds_mat_off + 2u * MPT_LDS_MATS_N;
+    const uint32_t cfg_off = mpt_lds_cfg_off_f4(pp.scene.lds_mat_off);
     if (threadIdx.x == 0) {
         announce_resident(pp);
         lds_raw[cfg_off + 0] = make_float4(pp.cam.x, pp.cam.y, pp.cam.z, pp.W);

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 namespace mpt_lbvh {
@@ -167,9 +168,13 @@ __global__ void k_sah_init(const uint32_t* count /* device word, or null */, uin
 // from the device: their grids are sized from an upper bound, the host does not wait for the counts), the push counters start
 // from zero, and the counts go to a slot of pinned host memory with a stamp behind them — the host reads them one or two
 // levels LATER, to size the grids of the levels it enqueues while the device is busy with this one (run_sah).
-__global__ void k_sah_flip(SahState* st, uint32_t level, uint32_t stamp, volatile uint32_t* host_slot) {
+// cover_*: the task counts the host sized this level's grids for (upper bounds, run_sah).  Counts beyond them would be dropped without a
+// trace and leave a malformed tree: the stamp then carries MPT_SAH_STAMP_OVERFLOW and the host fails the build.
+#define MPT_SAH_STAMP_OVERFLOW 0x8000u
+__global__ void k_sah_flip(SahState* st, uint32_t level, uint32_t stamp, volatile uint32_t* host_slot, uint32_t cover_mid, uint32_t cover_big, uint32_t cover_small) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t a = st->n_next, b = st->n_next_big, c = st->n_next_small;
+    if (a > cover_mid || b > cover_big || c > cover_small) stamp |= MPT_SAH_STAMP_OVERFLOW;
     st->cur[0] = a;
     st->cur[1] = b;
     st->cur[2] = c;
@@ -882,12 +887,16 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
     auto wait_slot = [&](int level, uint32_t out[3]) -> hipError_t {   // the counts of `level`, once k_sah_flip(level) has run
         volatile uint32_t* sl = slots + 4 * (level & 7);
         const uint32_t want = epoch | (uint32_t)(level + 1);
+        const auto t0 = std::chrono::steady_clock::now();
         for (unsigned long long spin = 0;; ++spin) {
-            if (sl[3] == want) break;
+            const uint32_t seen = sl[3];
+            if (seen == want) break;
+            if (seen == (want | MPT_SAH_STAMP_OVERFLOW)) return hipErrorLaunchOutOfResources;   // a level had more tasks than its grids covered (k_sah_flip)
             if ((spin & 0xFFFu) == 0xFFFu) {
                 const hipError_t q = hipStreamQuery(stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return q;
-                if (q == hipSuccess && sl[3] != want) return hipErrorUnknown;   // the stream is drained and the stamp never came
+                if (q == hipSuccess && (sl[3] & ~MPT_SAH_STAMP_OVERFLOW) != want) return hipErrorUnknown;   // the stream is drained and the stamp never came
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return hipErrorLaunchTimeOut;   // (a level takes < 1 ms: a kernel hangs)
             }
         }
         out[0] = sl[0];
@@ -900,7 +909,8 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
     bool done = false;
     int level = 0;
     for (; level < 4096 && !done; ++level) {
-        hipLaunchKernelGGL(k_sah_flip, dim3(1), dim3(64), 0, stream, T.st, (uint32_t)level, epoch | (uint32_t)(level + 1), (volatile uint32_t*)(d_pin + 64 + 4 * (level & 7)));
+        hipLaunchKernelGGL(k_sah_flip, dim3(1), dim3(64), 0, stream, T.st, (uint32_t)level, epoch | (uint32_t)(level + 1), (volatile uint32_t*)(d_pin + 64 + 4 * (level & 7)),
+                           b_mid, b_big, b_small);
         if (b_big) {
             const uint32_t chunks = max_items / MPT_SAH_CHUNK + b_big;   // >= sum of ceil(items / chunk) over the level's big tasks
             hipLaunchKernelGGL(k_big_prep, dim3(1), dim3(1024), 0, stream, (const SahTask*)big_a, (const SahState*)T.st, bigs, coff);

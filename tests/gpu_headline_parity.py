@@ -7,7 +7,11 @@ oracle, every float of the HDR sum compared bit for bit (the oracle needs ~8 s o
   CROSS=1 (with BVH=device) also renders the reference's tree and prints / checks the per-pixel L2 and the ray-count delta
                            between the two trees' images at full size: the trees are equal up to ties (a ray that hits two
                            primitives at the same t keeps the one its tree visits first), so the images are NOT bit-identical
-                           and the stated tolerance of north_star (per-pixel L2 < 1e-3) is what is asserted."""
+                           and the stated tolerance of north_star (per-pixel L2 < 1e-3) is what is asserted.
+  ASYNC=1                  the 256 spp are issued as bench.py's timed steps are: TWO back-to-back mpt_render_async calls of 256 spp each
+                           (samples 0..255 and 256..511, one per render lane: the second trace kernel starts behind the residency gate
+                           while the first still runs, both are the k_wavelocal_corun instantiation, the resolve of the first runs beside
+                           the second), then one mpt_wait; the oracle renders the same 512 samples into one sum (VERDICT r4 weak #2c)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,15 +26,26 @@ buf = host.make_ready(ctx, sc, host.BVH_DEVICE if BVH == "device" else host.BVH_
 u = host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount())
 ctx.resize(W, H); ctx.set_uniforms(u); ctx.clear_sum(); ctx.reset_stats()
 SCENE_PIPE = int(os.environ.get("PIPE", str(capi.DEFAULT_PIPELINE)))
-ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=spp, seed=(1, 0), pipeline=SCENE_PIPE)
+ASYNC = bool(os.environ.get("ASYNC"))
+total_spp = spp
+if ASYNC:
+    kw = dict(rng_mode=capi.RNG_PHILOX, max_depth=8, seed=(1, 0), pipeline=SCENE_PIPE)
+    ctx.render_async(sample_begin=0, sample_count=spp, **kw)      # lane 0
+    ctx.render_async(sample_begin=spp, sample_count=spp, **kw)    # lane 1, submitted while lane 0's trace kernel runs
+    ctx.wait()
+    total_spp = 2 * spp
+else:
+    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=spp, seed=(1, 0), pipeline=SCENE_PIPE)
 got = ctx.read_sum(); s = ctx.stats()
 t0 = time.time()
 ref, ct = ob.render(ob.Uniforms.from_buffer_copy(bytes(u)), buf, rng_mode=ob.RNG_PHILOX, max_depth=8, accumulate=1,
-                    sample_count=spp, seed=(1, 0), threads=int(os.environ.get("THREADS", "16")))
+                    sample_count=total_spp, seed=(1, 0), threads=int(os.environ.get("THREADS", "16")))
 dt = time.time() - t0
 same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
-l2 = float(np.sqrt(np.mean(np.sum((got[..., :3] / spp - ref[..., :3] / spp) ** 2, -1))))
-print("tree %s (%d nodes), pipeline %d, re-traced in reference order %d, parked %d" % (BVH, len(buf[0]), SCENE_PIPE, s["exact_retraces"], s["tree_parked"]))
+l2 = float(np.sqrt(np.mean(np.sum((got[..., :3] / total_spp - ref[..., :3] / total_spp) ** 2, -1))))
+print("tree %s (%d nodes), pipeline %d, %s, re-traced in reference order %d, parked %d" % (
+    BVH, len(buf[0]), SCENE_PIPE, "two overlapped mpt_render_async of %d spp (trace launches %d)" % (spp, s["trace_launches"]) if ASYNC else "one mpt_render",
+    s["exact_retraces"], s["tree_parked"]))
 print("GPU %.1f ms (%d rays), oracle %.1f s (%d rays): bit-identical=%s, per-pixel L2 = %.3g, differing floats = %d" % (
     s["total_ms"], s["rays"], dt, ct["rays"], same, l2, int((got != ref).sum())))
 ok = same and s["rays"] == ct["rays"]

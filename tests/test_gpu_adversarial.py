@@ -27,10 +27,11 @@ def _same(a, b):
     np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_config3_4k_shard_crosses_a_pass_boundary(gpu_ctx):
+@pytest.mark.parametrize("tree", ["reference", "device"])
+def test_config3_4k_shard_crosses_a_pass_boundary(gpu_ctx, tree):
     from metalpathtracer_amd import capi
     W, H = 3840, 2160
-    buf, uo = setup(gpu_ctx, "bunny20.xml", W, H)
+    buf, uo = setup_tree(gpu_ctx, "bunny20.xml", W, H, tree)   # (both tree routes: the device-built tree is what --bvh auto renders)
     kw = dict(rng_mode=capi.RNG_PHILOX, max_depth=8, seed=(1, 0))
     shard = dict(shard_rank=7, shard_count=8)
     # ---- the config's own size: 1/8 of the tiles, 1030 spp = passes of 1024 + 6 samples --------------------------------

@@ -11,7 +11,7 @@ import pytest
 
 from conftest import CORNELL_CAM, host_scene
 from oracle import binding as ob
-from test_gpu_parity import _heightfield_obj, setup
+from test_gpu_parity import _heightfield_obj, setup, setup_tree
 
 pytestmark = pytest.mark.gpu
 
@@ -172,12 +172,14 @@ def test_million_triangle_config_matches_the_oracle(gpu_ctx, million_triangle_sc
         assert gpu_ctx.stats()["rays"] == ct["rays"]
 
 
-def test_bunny20_full_size_properties(gpu_ctx):
+@pytest.mark.parametrize("tree", ["reference", "device"])
+def test_bunny20_full_size_properties(gpu_ctx, tree):
     """configs[2] at its full 1920x1080: determinism, sample-range and shard additivity, closest-first == reference
-    order, and a band of rows against the oracle."""
+    order, and a band of rows against the oracle — on the reference's own tree and on the device-built one (leaves of <= 2, padded
+    own boxes: what bench.py's bunny x20 workload and `--bvh auto` render; the oracle walks the tree read back from the device)."""
     from metalpathtracer_amd import capi
     W, H = 1920, 1080
-    buf, uo = setup(gpu_ctx, "bunny20.xml", W, H)
+    buf, uo = setup_tree(gpu_ctx, "bunny20.xml", W, H, tree)
     kw = dict(rng_mode=capi.RNG_PHILOX, max_depth=8, seed=(1, 0))
     gpu_ctx.clear_sum()
     gpu_ctx.render(sample_count=4, **kw)
