@@ -468,8 +468,13 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     MPT_LB(sc.alloc(&mtable, 2 * (size_t)n));
     hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, stream, d_mats_in, n, mk, mi);
     {
-        // (all 64 bits: sorting on bits [32, 64) only — four radix passes instead of eight — came back wrong from hipcub on this
-        //  toolchain: images off in 1.5 % of the pixels, once an abort; not pursued)
+        // All 64 bits.  hipcub::DeviceRadixSort::SortPairs over bits [32, 64) of 64-bit keys — four radix passes instead of eight — is
+        // WRONG on this toolchain (ROCm 7.2.0, gfx950) from a few thousand items on: the keys it returns are not even a permutation of
+        // its input (tests/experiments/hipcub_partial_bits.hip, run on MI355X: 4,971 / 99,362 / 1,000,003 items, material hashes and random
+        // keys, its own queried temporary size, canaries behind every buffer intact, input untouched; 5 items: right).  That is what round
+        // 4's experiment hit: material ids from garbage keys — images off in 1.5 % of the pixels, and once ids far outside the table, a
+        // memory fault inside this build and the abort of gpurun_out/r04/s46_tests.log.  The same program finds every range the product
+        // DOES use right at all four sizes: [0, 64) here, [0, 63) (mpt_lbvh.h), [0, 13) and [0, 8) on 32-bit keys below (docs/HISTORY.md).
         size_t bytes = 0;
         MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, stream));
         char* tmp;

@@ -41,11 +41,13 @@ __device__ __forceinline__ F3 cross3(F3 a, F3 b) {
 // is the fma chain alone — rcp_chain() below, 7 instructions, the SAME operations in the same order.  The range in
 // which the two agree bit for bit is not argued but MEASURED on the device over all 2^32 operands (k_kat_rcp,
 // tests/test_gpu_parity.py::test_reciprocal_chain_equals_ieee_division_on_all_operands): every x with
-// MPT_RCP_LO <= |x| <= MPT_RCP_HI.  mpt_rcp() takes the chain inside that range and the full expansion outside, under
-// a branch that whole waves skip.  MPT_FAST_RCP: 0 = always the full expansion (rounds 1-4), 1 = guarded chain,
-// 2 = unguarded chain (pricing experiment only: wrong for operands outside the range).
+// MPT_RCP_LO <= |x| <= MPT_RCP_HI.  mpt_rcp() takes the chain when EVERY lane of the wave is inside that range (one ballot, one
+// scalar branch) and the full expansion otherwise.  MPT_FAST_RCP: 3 = that wave-uniform guard (the default: scene.xml 16.91 ->
+// 16.80 ms, the closest-first kernel unchanged), 0 = always the full expansion (rounds 1-4), 1 = guarded per lane (-0.5 %: the
+// exec-mask bookkeeping eats the gain), 2 = unguarded (pricing experiment only, wrong outside the range: -1.7 %, the price of the
+// 22 divisions of k_wavelocal).
 #ifndef MPT_FAST_RCP
-#define MPT_FAST_RCP 0
+#define MPT_FAST_RCP 3
 #endif
 #define MPT_RCP_LO 1.1754943508222875e-38f   // 2^-126 (smallest normal)
 #define MPT_RCP_HI 8.5070591730234616e+37f   // 2^126
@@ -63,12 +65,33 @@ __device__ __forceinline__ bool rcp_chain_exact(float x) { return fabsf(x) >= MP
 __device__ __forceinline__ float mpt_rcp(float x) {
 #if MPT_FAST_RCP == 2
     return rcp_chain(x);
+#elif MPT_FAST_RCP == 3   // wave-uniform guard: a wave whose operands are all inside the range takes the chain, any other the full expansion
+    if (__builtin_expect(__ballot(!rcp_chain_exact(x)) == 0ull, 1)) return rcp_chain(x);
+    return 1.0f / x;
 #elif MPT_FAST_RCP == 1
     float r = rcp_chain(x);
     if (__builtin_expect(!rcp_chain_exact(x), 0)) r = 1.0f / x;
     return r;
 #else
     return 1.0f / x;
+#endif
+}
+// 1/x, 1/y, 1/z under ONE guard (closest_hit_resume: PathTracing.h:61, `1.0 / r.direction[i]` for the three axes)
+__device__ __forceinline__ void mpt_rcp3(float x, float y, float z, float& ix, float& iy, float& iz) {
+#if MPT_FAST_RCP == 3
+    if (__builtin_expect(__ballot(!(rcp_chain_exact(x) && rcp_chain_exact(y) && rcp_chain_exact(z))) == 0ull, 1)) {
+        ix = rcp_chain(x);
+        iy = rcp_chain(y);
+        iz = rcp_chain(z);
+        return;
+    }
+    ix = 1.0f / x;
+    iy = 1.0f / y;
+    iz = 1.0f / z;
+#else
+    ix = mpt_rcp(x);
+    iy = mpt_rcp(y);
+    iz = mpt_rcp(z);
 #endif
 }
 // normalize = v * (1 / sqrt(dot(v,v))) — same definition as the oracle (see its comment).
@@ -257,18 +280,10 @@ __device__ __forceinline__ Prim3 load_prim(const SceneDev& sc, LdsNodes lds, uin
 template <bool COUNT>
 __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint32_t first, uint32_t count, F3 o, F3 d,
                                           float& best_t, int& best_prim, WorkCount& wc) {
-#ifdef MPT_WL_PREFETCH   // (experiment) primitive k + 1 is loaded while k is tested
-    Prim3 nxt = load_prim(sc, lds, first);
-#endif
     for (uint32_t k = 0; k < count; ++k) {
         // the three 16-byte loads of a primitive are issued together (the third is used by triangles only, but a
         // load that waits for the type check costs a second L2 round trip per primitive)
-#ifdef MPT_WL_PREFETCH
-        const Prim3 pr = nxt;
-        if (k + 1u < count) nxt = load_prim(sc, lds, first + k + 1u);
-#else
         const Prim3 pr = load_prim(sc, lds, first + k);
-#endif
         const float4 p0 = pr.p0, p1 = pr.p1, p2 = pr.p2;
         if (COUNT) {
             wc.prim_tests++;
@@ -279,24 +294,7 @@ __device__ __forceinline__ void leaf_test(const SceneDev& sc, LdsNodes lds, uint
             F3 v0 = f3(p0.x, p0.y, p0.z), e1 = f3(p1.x, p1.y, p1.z), e2 = f3(p2.x, p2.y, p2.z);
             F3 h = cross3(d, e2);
             float a = dot3(e1, h);
-#ifdef MPT_WL_TRI_FLAT
-            // (experiment) without early-outs, as ot_test_prim in mpt_ordered.h: the same operations give the same values; where the
-            // reference leaves early the rest is computed from garbage and discarded by `hit`
-            {
-                const float f = 1.0f / a;
-                const F3 s = o - v0;
-                const float u = f * dot3(s, h);
-                const F3 q = cross3(s, e1);
-                const float v = f * dot3(d, q);
-                const float tt = f * dot3(e2, q);
-                const bool hit = fabsf(a) > 1e-5f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && tt > 0.0001f && tt < best_t;
-                best_t = hit ? tt : best_t;
-                best_prim = hit ? (int)(first + k) : best_prim;
-            }
-            if (false) {
-#else
             if (fabsf(a) > 1e-5f) {
-#endif
                 float f = mpt_rcp(a);
                 F3 s = o - v0;
                 float u = f * dot3(s, h);
@@ -355,7 +353,8 @@ template <bool COUNT, bool ALL_LDS, bool BUDGETED>
 __device__ __forceinline__ bool closest_hit_resume(const SceneDev& sc, LdsNodes lds_nodes, F3 o, F3 d, uint32_t& node,
                                                    float& best_t, int& best_prim, uint32_t budget, WorkCount& wc,
                                                    uint32_t min_active = 0u) {
-    const float idx = mpt_rcp(d.x), idy = mpt_rcp(d.y), idz = mpt_rcp(d.z);  // PathTracing.h:61 (per call there): 1.0 / r.direction[i]
+    float idx, idy, idz;
+    mpt_rcp3(d.x, d.y, d.z, idx, idy, idz);   // PathTracing.h:61 (per call there): 1.0 / r.direction[i]
     const uint32_t n_nodes = sc.n_nodes, n_lds = sc.n_lds_nodes;
     // A direction with a NaN component (normalize of a zero vector: e.g. a refraction at the critical angle whose
     // discriminant rounds below zero) hits nothing — every sphere / triangle test mixes all three components and ends

@@ -139,8 +139,6 @@ struct mpt_ctx {
     bool have_scene = false;
     // the product's own tree (mpt_accel.h) for the closest-first pipeline; it shares d_prims with the threaded tree
     float4* d_acc_nodes = nullptr;
-    float4* d_acc_qnodes = nullptr;   // the same nodes in the 64-byte form the walk fetches from global memory (mpt_ordered.h)
-    uint32_t n_acc_float = 0;         // ... of which so many could not be quantised and are fetched as floats (degenerate boxes)
     float4* d_refleaf = nullptr;
     float4* d_refbox = nullptr;       // the box of its reference leaf PER PRIMITIVE, 2 float4 each: the final check of the closest-first walk needs no look-up through the primitive
     float4* d_always = nullptr;
@@ -392,7 +390,6 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipFree(ctx->d_prims);
     hipFree(ctx->d_mats);
     hipFree(ctx->d_acc_nodes);
-    hipFree(ctx->d_acc_qnodes);
     hipFree(ctx->d_refbox);
     hipFree(ctx->d_refleaf);
     hipFree(ctx->d_always);
@@ -473,8 +470,6 @@ static void size_lds_images(mpt_ctx* ctx) {
     }
 }
 
-// The 64-byte form of the own tree's nodes (k_quantize_nodes, mpt_ordered.h): derived on the device from the float nodes, whichever
-// route made them.
 // the per-primitive reference-leaf boxes of an uploaded scene (k_prim_refbox, mpt_devbuild.h)
 static int make_prim_refbox(mpt_ctx* ctx) {
     hipFree(ctx->d_refbox);
@@ -487,26 +482,6 @@ static int make_prim_refbox(mpt_ctx* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MPT_OK;
 }
-static int quantize_acc_nodes(mpt_ctx* ctx) {
-    hipFree(ctx->d_acc_qnodes);
-    ctx->d_acc_qnodes = nullptr;
-    ctx->n_acc_float = 0;
-    if (!MPT_OT_QNODES) return MPT_OK;   // (the experiment is compiled out: no second copy of the nodes)
-    const uint32_t n = std::max(ctx->n_acc_nodes, 1u);
-    ctx->n_acc_float = 0;
-    HIPCHK(hipMalloc(&ctx->d_acc_qnodes, (size_t)n * 64 + 64));   // (+ the counter of nodes left as floats, behind the nodes)
-    uint32_t* d_count = (uint32_t*)(ctx->d_acc_qnodes + 4u * (size_t)n);
-    HIPCHK(hipMemsetAsync(d_count, 0, 4, ctx->stream));
-    if (ctx->n_acc_nodes) {
-        hipLaunchKernelGGL(k_quantize_nodes, dim3((ctx->n_acc_nodes + 255u) / 256u), dim3(256), 0, ctx->stream, (const float4*)ctx->d_acc_nodes, ctx->n_acc_nodes,
-                           ctx->d_acc_qnodes, d_count);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&ctx->n_acc_float, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    return MPT_OK;
-}
-
 static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, const float* prims,
                                 const float* mats, const int32_t* prim_idx, uint64_t n_prims) {
     if (!ctx) return MPT_ERR_INVALID_ARG;
@@ -834,10 +809,6 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
     ctx->n_prims = (uint32_t)(dprims.size() / 12);
     ctx->n_mats = (uint32_t)(mat_table.size() / 8);
     ctx->n_acc_nodes = (uint32_t)(acc_nodes.size() / MPT_ACCEL_NODE_FLOATS);
-    {
-        int qrc = quantize_acc_nodes(ctx);
-        if (qrc) return qrc;
-    }
     ctx->n_always = (uint32_t)(always.size() / 20);
     ctx->n_ref_leaves = (uint32_t)(refleaf.size() / 8);
     {
@@ -980,7 +951,6 @@ static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack
     s.n_lds_nodes = 0;
     s.n_lds_prims = ctx->ot_lds_prims;
     a.nodes = ctx->d_acc_nodes;
-    a.qnodes = ctx->d_acc_qnodes;
     a.refleaf = ctx->d_refleaf;
     a.refbox = ctx->d_refbox;
     a.always = ctx->d_always;
@@ -1064,6 +1034,29 @@ static int ensure_tile_order(mpt_ctx* ctx, uint32_t rank, uint32_t nranks, uint3
         if (ctx->tile_order_mode == 2) tl = n_local - 1u - k;  // bottom-up row-major
         const uint32_t T = tl * nranks + rank;
         xy[k] = (T % tiles_x) | ((T / tiles_x) << 16);
+    }
+    if (ctx->tile_order_mode == 3 && n_local >= MPT_NGROUP) {
+        // XCD stripes (round 5): claim range g — the workgroups with blockIdx % 8 == g, one XCD under round-robin placement, with an L2
+        // of its own — owns the tiles at positions k % 8 == g of this table (range_chunk_to_path_chunk).  Row-major order gives every
+        // range every 8th tile of every row: all eight L2s see the whole scene.  Here the rank's tiles are cut into eight vertical
+        // stripes of equal tile count (sky, ground and geometry in each: balanced) and range g gets stripe g, top-down: the rays of one
+        // XCD start in one part of the scene and its L2 holds that part of the tree.  Ranges that run dry steal from the next, as ever.
+        std::vector<uint32_t> col(xy);   // the rank's tiles, column-major
+        std::sort(col.begin(), col.end(), [](uint32_t a, uint32_t b) {
+            const uint32_t ax = a & 0xFFFFu, bx = b & 0xFFFFu;
+            return ax != bx ? ax < bx : (a >> 16) < (b >> 16);
+        });
+        size_t at = 0;
+        for (uint32_t g = 0; g < MPT_NGROUP; ++g) {
+            const uint32_t n_g = (n_local - g + MPT_NGROUP - 1u) / MPT_NGROUP;   // = range_paths' tile count of range g
+            std::vector<uint32_t> stripe(col.begin() + at, col.begin() + at + n_g);
+            at += n_g;
+            std::sort(stripe.begin(), stripe.end(), [](uint32_t a, uint32_t b) {   // top-down, left to right inside the stripe
+                const uint32_t ay = a >> 16, by = b >> 16;
+                return ay != by ? ay < by : (a & 0xFFFFu) < (b & 0xFFFFu);
+            });
+            for (uint32_t j = 0; j < n_g; ++j) xy[(size_t)j * MPT_NGROUP + g] = stripe[j];
+        }
     }
     hipFree(ctx->d_tile_xy);
     ctx->d_tile_xy = nullptr;
@@ -1802,10 +1795,6 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     ctx->d_mats = b.mats;
     ctx->d_acc_nodes = b.acc_nodes;
     ctx->n_acc_nodes = b.n_acc_nodes;
-    {
-        int qrc = quantize_acc_nodes(ctx);
-        if (qrc) return qrc;
-    }
     ctx->d_refleaf = b.refleaf;
     hipFree(ctx->d_refbox);
     ctx->d_refbox = b.refbox;
@@ -2034,7 +2023,7 @@ extern "C" int mpt_build_info(mpt_ctx* ctx, uint64_t out[8]) {
     if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
     const bool built = ctx->d_ref_bvh != nullptr;
     const uint64_t v[8] = {built ? ctx->n_prims : 0u, built ? ctx->n_ref_nodes : 0u, built ? ctx->built_leaf_max : 0u, MPT_AUTO_ORDERED_PRIMS,
-                           ctx->n_prims, ctx->n_nodes, ctx->n_mats, ctx->n_acc_float};
+                           ctx->n_prims, ctx->n_nodes, ctx->n_mats, 0u /* (was: nodes left unquantised by round 4's 64-byte node experiment) */};
     memcpy(out, v, sizeof v);
     return MPT_OK;
 }

@@ -466,13 +466,7 @@ __global__ __launch_bounds__(1024, MPT_MIN_WAVES) void k_megakernel(PassParams p
 // Result slots are written once and read once, much later, by the resolve kernel: streaming (non-temporal) accesses
 // keep them from evicting the ring records the trace kernel is about to pop.
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
-// Traffic experiments (round 4, DESIGN.md 8 "the traffic diet"): -DMPT_DIET_NOSLOT drops the slot store (WRONG image: the upper
-// bound of what any slot diet can win), -DMPT_DIET_RINGPLUS writes one more 16-byte word per push to ring 0, 25 % more ring traffic (what ring traffic costs).
 __device__ __forceinline__ void store_slot(float4* slots, uint32_t path, float r, float g, float b, float a) {
-#ifdef MPT_DIET_NOSLOT
-    if (r == 12345.678f) slots[path] = make_float4(r, g, b, a);   // (never true for a clamped colour: the store is compiled, not executed)
-    return;
-#endif
 #ifdef MPT_SLOTS_TEMPORAL
     slots[path] = make_float4(r, g, b, a);
 #else
@@ -539,20 +533,17 @@ __host__ __device__ __forceinline__ uint32_t mpt_lds_image_end_f4(uint32_t lds_m
 // Ring record (round 4, "the traffic diet"): 48 bytes that every ray needs — od, dt, ia — and 16 more (tl: the light gathered so
 // far) only for the rays that HAVE gathered light: L and alpha are all-zero bits until a path meets an emitter, which most bounce
 // rays of most scenes never have (a flag in ia says whether tl was written; the pop restores exact zeros otherwise).  The sample
-// index is recomputed from the path id.  Measured before building it (MPT_DIET_RINGPLUS / MPT_DIET_NOSLOT builds, in-kernel
-// clock stamped): 16 bytes MORE per push cost 3.0 % (19.23 -> 19.81 ms, clock 2.243 -> 2.203 GHz), dropping the result slots
-// altogether — the bound of any slot diet — gains 3.2 %.  -DMPT_WL_DIET=0 is round 3's 64-byte record.
-#ifndef MPT_WL_DIET
-#define MPT_WL_DIET 1
-#endif
+// index is recomputed from the path id.  Measured before building it (round 4's traffic what-if builds, in-kernel clock stamped: 16
+// bytes MORE per push cost 3.0 % (19.23 -> 19.81 ms, clock 2.243 -> 2.203 GHz), dropping the result slots altogether — the bound of
+// any slot diet — gains 3.2 %; tests/experiments/rejected_r04_flags.h).  (Round 3's 64-byte record is gone from the source.)
 #define MPT_RING_HAS_LIGHT 0x100u
 struct WaveRings {             // [n_waves][MPT_WL_LEVELS][MPT_WL_RING] records in five arrays of 16-byte fields, ONE allocation: the kernel
     float4* base;              // keeps one base pointer and the array length in scalar registers instead of five pointers
     uint32_t n;                // records per array = n_waves * MPT_WL_LEVELS * MPT_WL_RING
     __host__ __device__ float4* od() const { return base; }                        // (o.xyz, d.x)
     __host__ __device__ float4* dt() const { return base + n; }                    // (d.y, d.z, thr.r, thr.g)
-    __host__ __device__ float4* tl() const { return base + 2u * (size_t)n; }       // MPT_WL_DIET: (L.rgb, L.a), written only with MPT_RING_HAS_LIGHT; else (thr.b, L.rgb)
-    __host__ __device__ uint4* ia() const { return (uint4*)(base + 3u * (size_t)n); }  // MPT_WL_DIET: (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT); else (path, L.a bits, pixel, sample | bounce << 27)
+    __host__ __device__ float4* tl() const { return base + 2u * (size_t)n; }       // (L.rgb, L.a), written only with MPT_RING_HAS_LIGHT
+    __host__ __device__ uint4* ia() const { return (uint4*)(base + 3u * (size_t)n); }  // (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT); ring 0 (hits): see ring_push_hit
     __host__ __device__ uint4* tv() const { return (uint4*)(base + 4u * (size_t)n); }  // rings >= 1: (next node, best t bits, best primitive, 0)
 };
 // what a push writes / a pop reads (both pipelines' rings use the same record)
@@ -566,21 +557,15 @@ __device__ __forceinline__ uint32_t sample_of_path(const PassParams& pp, uint32_
 __device__ __forceinline__ void ring_push(const WaveRings& ring, uint32_t at, const PathState& ps, const PathRngDev& g) {
     ring.od()[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
     ring.dt()[at] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-#if MPT_WL_DIET
     const bool lit = ring_has_light(ps);
     ring.ia()[at] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
     if (lit) ring.tl()[at] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
-#else
-    ring.tl()[at] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-    ring.ia()[at] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
-#endif
 }
 __device__ __forceinline__ void ring_pop(const PassParams& pp, const WaveRings& ring, uint32_t at, PathState& ps, PathRngDev& g) {
     const float4 a = ring.od()[at], b = ring.dt()[at];
     const uint4 ia = ring.ia()[at];
     ps.o = f3(a.x, a.y, a.z);
     ps.d = f3(a.w, b.x, b.y);
-#if MPT_WL_DIET
     ps.thr = f3(b.z, b.w, __uint_as_float(ia.x));
     ps.path = ia.y;
     g.pixel = ia.z;
@@ -593,31 +578,15 @@ __device__ __forceinline__ void ring_pop(const PassParams& pp, const WaveRings& 
         ps.L = f3(cc.x, cc.y, cc.z);
         ps.La = cc.w;
     }
-#else
-    const float4 cc = ring.tl()[at];
-    ps.thr = f3(b.z, b.w, cc.x);
-    ps.L = f3(cc.y, cc.z, cc.w);
-    ps.La = __uint_as_float(ia.y);
-    ps.path = ia.x;
-    ps.bounce = ia.w >> 27;
-    g.pixel = ia.z;
-    g.sample = ia.w & 0x07FFFFFFu;
-#endif
     g.lit_seed = 0;
     if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
 }
-// Ring 0 as a ring of HITS (round 4, -DMPT_WL_HITRING=0 for round 3's order of work).  Round 3 shaded a ray where its closest hit
+// Ring 0 as a ring of HITS (round 4).  Round 3 shaded a ray where its closest hit
 // was found: in a step of 64 rays about half hit a surface and half the sky, so the 250-instruction hit branch ran at half
 // width — 8 wave-instructions per hit.  Now the step that finds a hit pushes the HIT (the ray, its t and primitive) to ring 0,
 // and the step that pops 64 hits shades all of them first, at full width, and traces the 64 bounce rays right away: the same
 // one ring hop per bounce as before, the same 48 (+ 16) bytes (t takes the place of the pixel index, which is recomputed from
 // the path id, and the primitive shares a word with the bounce count), and every ray sees the same arithmetic in the same order.
-#ifndef MPT_WL_HITRING
-#define MPT_WL_HITRING 1
-#endif
-#if MPT_WL_HITRING && !MPT_WL_DIET
-#error "MPT_WL_HITRING needs the MPT_WL_DIET record"
-#endif
 // record: od, dt as above; ia = (thr.b bits, path, t bits | light flag in the sign bit (t > 0), primitive | bounce << 27); tl as above
 __device__ __forceinline__ void ring_push_hit(const WaveRings& ring, uint32_t at, const PathState& ps, float t, uint32_t prim) {
     ring.od()[at] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
@@ -831,11 +800,9 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
         int best_prim = -1;
         uint32_t budget = 0xFFFFFFFFu, min_active = 0u;
         bool fresh = false;  // this lane starts a new closest-hit query (primary ray or ring-0 record)
-#if MPT_WL_HITRING
         bool need_shade = false;   // this lane popped a hit from ring 0
         float hit_t = 0.0f;
         int hit_prim = -1;
-#endif
         if (level < 0) {
             fresh = true;
             // 64 new paths = one 8x8 pixel tile at one sample index: everything about the tile is wave-uniform, and its
@@ -913,12 +880,8 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
                 const uint32_t at = wbase + my_ring * MPT_WL_RING + my_off;
                 uint4 tv = make_uint4(0u, 0u, 0u, 0u);
                 if (my_ring > 0u) tv = ring.tv()[at];   // (issued with the record's other loads, ahead of ring_pop's conditional one)
-#if MPT_WL_HITRING
                 ring_pop_hit(ring, at, ps, hit_t, hit_prim);
                 need_shade = my_ring == 0u;
-#else
-                ring_pop(pp, ring, at, ps, g);
-#endif
                 if (my_ring > 0u) {
                     node = tv.x;
                     best_t = __uint_as_float(tv.y);
@@ -929,7 +892,6 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
                 valid = true;
             }
         }
-#if MPT_WL_HITRING
         // ---- the hits popped from ring 0 are shaded first — all 64 lanes of a ring-0 step — and leave their bounce rays in `ps` ------
         if (need_shade) {
             uint32_t px, py, sidx;
@@ -943,7 +905,6 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
                 valid = false;
             }
         }
-#endif
         // the last ring never has a budget; a ring whose budget is "none" runs the plain (unsynchronised) loop
         // (the last ring has no trip budget; with a min_active rule its stragglers go back on top of the same ring)
         const bool budgeted = level >= 0 && (level < (int)MPT_WL_LEVELS || min_active != 0u) &&
@@ -980,17 +941,11 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
             }
 #endif
             if (done) {
-#if MPT_WL_HITRING
                 alive = best_prim >= 0;   // a hit: to ring 0 as it is, shaded by the step that pops it
                 if (!alive) {             // the sky ends the path (PathTracing.h:225-232)
                     shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, -1);
                     store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
                 }
-#else
-                alive = shade_bounce(pp.scene, lds_nodes, pp.sp, g, ps, best_t, best_prim);
-                if (!alive)
-                    store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
-#endif
             } else {
                 parked = true;
             }
@@ -1000,14 +955,7 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
         if (am != 0ull) {  // survivors are fresh rays -> ring 0
             if (alive) {
                 const uint32_t at = wbase + ((head[0] + cnt[0] + wave_rank(am)) & M);
-#if MPT_WL_HITRING
                 ring_push_hit(ring, at, ps, best_t, (uint32_t)best_prim);
-#else
-                ring_push(ring, at, ps, g);
-#endif
-#ifdef MPT_DIET_RINGPLUS   // (ring.tv() of ring 0 is never read: fresh rays carry no traversal state)
-                ring.tv()[at] = make_uint4(ps.path, 0u, 0u, 0u);
-#endif
             }
             cnt[0] += (uint32_t)__popcll(am);
         }
@@ -1021,11 +969,7 @@ __device__ __forceinline__ void wavelocal_body(const PassParams& pp, const WaveR
                 }
             if (parked) {
                 const uint32_t at = wbase + (uint32_t)park_ring * MPT_WL_RING + ((h + c + wave_rank(pm)) & M);
-#if MPT_WL_HITRING
                 ring_push_hit(ring, at, ps, 0.0f, 0u);   // (a parked ray: its traversal state is in tv)
-#else
-                ring_push(ring, at, ps, g);
-#endif
                 ring.tv()[at] = make_uint4(node, __float_as_uint(best_t), (uint32_t)best_prim, 0u);
             }
 #pragma unroll

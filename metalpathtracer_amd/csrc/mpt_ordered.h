@@ -58,33 +58,13 @@
 #ifndef MPT_OT_MLEVELS
 #define MPT_OT_MLEVELS 2u                 // tree-walk rings: rays sorted by the walk they have already done (budgets).
 #endif                                    // bunny x20, 256 spp: 2 rings 76.8 ms, 3 rings 77.9, 4 rings 82.4
-// Ring R (fresh bounce rays) as EIGHT rings keyed by the direction octant (sign bits of d): the rays of a step then share
-// the order in which they visit a node's children, and — the rings of a wave are fed by consecutive samples of one 8x8 pixel
-// tile — origins that lie close together: the walks of a step look alike, which is what the node loop's lane utilisation and
-// the vector L1 want.  MEASURED AND REJECTED (round 4): bunny x20 71.4 ms against 64.3 with one ring, the 1 M-triangle
-// shard 148 against 133 — the rays of a wave wait in eight rings instead of one (four times the live records: more of them
-// fall out of the L2) and the steps gain nothing back: every lane still fetches its own node, so the octant does not lower
-// the tag look-ups per load instruction.  Kept behind the flag for the record; 0 = one ring (the product).
-#ifndef MPT_OT_OCT
-#define MPT_OT_OCT 0
-#endif
-#define MPT_OT_NR (MPT_OT_OCT ? 8u : 1u)  // fresh-ray rings
-// Ring R as a ring of HITS (round 4; as ring 0 of k_wavelocal, mpt_kernels.h MPT_WL_HITRING): a step that has a ray's final closest
-// hit pushes the hit (ray, t, primitive) to ring R instead of shading it at whatever width the step happens to have — the always-list
-// sphere hits of a top test, the finished walks of a ring-M step, the re-traced rays of ring E — and the step that pops 64 hits
-// shades them all at full width, then runs the top test on the 64 bounce rays.  Same number of ring hops, same record size.
-#ifndef MPT_OT_REFBOX
-#define MPT_OT_REFBOX 1   // 1: the final check reads the reference leaf's box by primitive index (one round trip); 0: through the primitive record (two)
-#endif
-#ifndef MPT_OT_LEAF2
-#define MPT_OT_LEAF2 1   // 1: the first two primitives of a leaf are loaded together
-#endif
-#ifndef MPT_OT_HITRING
-#define MPT_OT_HITRING 1
-#endif
-#if MPT_OT_HITRING && (!MPT_WL_DIET || MPT_OT_OCT)
-#error "MPT_OT_HITRING needs the MPT_WL_DIET record and one fresh-ray ring"
-#endif
+// Ring R holds HITS (round 4; as ring 0 of k_wavelocal, mpt_kernels.h): a step that has a ray's final closest hit pushes the hit (ray,
+// t, primitive) to ring R instead of shading it at whatever width the step happens to have — the always-list sphere hits of a top
+// test, the finished walks of a ring-M step, the re-traced rays of ring E — and the step that pops 64 hits shades them all at full
+// width, then runs the top test on the 64 bounce rays.  Same number of ring hops, same record size.  (Rejected variants of the rings
+// and of the node fetch — eight rings keyed by the direction octant, 64-byte quantised nodes, non-temporal pops and pushes, touch and
+// prefetch loads — are recorded with their code and numbers in tests/experiments/rejected_r04_flags.h and rejected_r05.h.)
+#define MPT_OT_NR 1u                      // fresh-ray rings
 #define MPT_OT_RINGS (MPT_OT_NR + 1u + MPT_OT_MLEVELS) // R (x NR) fresh rays, E reference-order walk, M0.. rays walking the tree
 #define MPT_OT_PARK 8u                    // stack entries a parked ray takes along (>= the LDS stack depth)
 #ifndef MPT_OT_EARLY
@@ -127,7 +107,7 @@ struct OtRings {              // [n_waves][MPT_OT_RINGS][MPT_WL_RING] records, s
     uint32_t n;               // records per array
     __host__ __device__ float4* od() const { return base; }                               // (o.xyz, d.x)
     __host__ __device__ float4* dt() const { return base + n; }                           // (d.y, d.z, thr.r, thr.g)
-    __host__ __device__ float4* tl() const { return base + 2u * (size_t)n; }              // as WaveRings (mpt_kernels.h): with MPT_WL_DIET (L.rgb, L.a), only for rays that have gathered light
+    __host__ __device__ float4* tl() const { return base + 2u * (size_t)n; }              // as WaveRings (mpt_kernels.h): (L.rgb, L.a), only for rays that have gathered light
     __host__ __device__ uint4* ia() const { return (uint4*)(base + 3u * (size_t)n); }     // ... and (thr.b bits, path, pixel, bounce | MPT_RING_HAS_LIGHT)
     __host__ __device__ uint4* tv() const { return (uint4*)(base + 4u * (size_t)n); }     // rings M: (best t bits, best primitive, next node / leaf of the walk, stack entries)
     __host__ __device__ uint4* sk(uint32_t k) const { return (uint4*)(base + (5u + k) * (size_t)n); }  // rings M: the walk's stack, two (key, ref) entries per field
@@ -139,27 +119,8 @@ struct OtBudgets {
     uint32_t inplace_min;                 // a primary / ring-R step whose top test sends at least this many lanes into the tree
 };                                        // walks it at once (as a ring-M0 step would) instead of parking them; 65 = never
 
-// Nodes that the walk fetches from GLOBAL memory come in a second, 64-byte form (round 4): the walk is bound by the tag
-// look-ups of the vector L1 — every lane fetches its own node, seven 16-byte loads each — and 64 bytes are four.  Measured
-// with a build that adds dummy loads of the same node (L1 hits): +3 loads per global node visit = +11.7 % on bunny x20, +7 =
-// +23.9 %; +30 vector instructions per node visit = +5.5 %.  Layout (k_quantize_nodes below):
-//   w0 = (o.x, o.y, o.z, s.x)   w1 = (s.y, s.z, bits(lo.x[4 x u8]), bits(lo.y[4]))   w2 = bits(lo.z[4], hi.x[4], hi.y[4], hi.z[4])   w3 = child[4]
-// child plane = fma(q, s, o) in fp32 — the quantiser VERIFIES with that very expression that every decoded box contains the
-// float box it stands for (lo planes rounded down, hi planes up), so nothing of the exactness argument above changes: the
-// boxes only grow (by < 1/255 of the node's extent per side).  A node with a plane that is not finite (degenerate input) or
-// an extent that overflows gets boxes that every ray enters (its children are then tested as always).  The nodes staged in
-// LDS stay floats (112 B).
-// MEASURED AND REJECTED (round 4): bunny x20 68.8 ms against 64.4 with float nodes, the 1 M-triangle shard 139.0 against 132.5,
-// scene.xml 23.2 against 22.5 — node visits +0.7 %, but the 57 vector instructions of the decode are paid by every trip in
-// which any lane is at a global node, and the three loads saved are worth less than the dummy-load experiment suggested
-// (those were hits under a pending miss of the same line).  A first version that tested one loaded word (an "unquantisable"
-// mark) before issuing the other loads cost a second round trip per visit: 72.6 ms.  Kept behind the flag; 0 = float nodes.
-#ifndef MPT_OT_QNODES
-#define MPT_OT_QNODES 0
-#endif
 struct AccelDev {
     const float4* nodes;    // MPT_OT_NODE_STRIDE float4 per node (7 used), breadth-first (mpt_accel.h)
-    const float4* qnodes;   // the same nodes, 4 float4 each (quantised child boxes)
     const float4* refleaf;  // 2 float4 per reference leaf: (bmin, 0) (bmax, 0)
     const float4* refbox;   // the same boxes per PRIMITIVE (2 float4 each; k_prim_refbox, mpt_devbuild.h): what the final check reads
     const float4* always;   // 5 float4 per sphere of the always list: (c, leaf<<1) (r, bits(index), bits(k), mat) (0,0,0, orig id)
@@ -233,7 +194,7 @@ struct OtNode {
 typedef const __attribute__((address_space(3))) char* LdsBytes;
 template <bool ALL_LDS>
 __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds, uint32_t n, const OtRay& r) {
-    static_assert(MPT_OT_NODE_STRIDE == 7u && !MPT_OT_QNODES, "MPT_OT_SIGNSEL addresses the 112-byte float node");
+    static_assert(MPT_OT_NODE_STRIDE == 7u, "MPT_OT_SIGNSEL addresses the 112-byte float node");
     OtNode nd;
     const uint32_t at = __umul24(n, 112u);   // (n < 2^24: checked where the launch is sized, ordered_layout_ok)
     // near planes at `at + s`, far planes at `(at + 48) - s`, the axis in the instruction's immediate offset (0 / 16 / 32): three
@@ -307,31 +268,6 @@ __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds,
         nd.hz = make_float4(f.x, f.y, f.z, f.w);
         nd.ref = make_uint4(__float_as_uint(g.x), __float_as_uint(g.y), __float_as_uint(g.z), __float_as_uint(g.w));
     } else {
-#if MPT_OT_QNODES
-        const float4* qq = ac.qnodes + 4u * (size_t)n;
-        const float4 w0 = qq[0], w1 = qq[1], w2 = qq[2], w3 = qq[3];
-        {   // (no branch on the loaded data: a test of w0 before the other three loads are issued costs a second round trip per visit —
-            //  measured: 72.6 ms instead of 64.7.  A node that cannot be quantised gets boxes that every ray enters, see k_quantize_nodes)
-            const uint32_t qlx = __float_as_uint(w1.z), qly = __float_as_uint(w1.w), qlz = __float_as_uint(w2.x), qhx = __float_as_uint(w2.y),
-                           qhy = __float_as_uint(w2.z), qhz = __float_as_uint(w2.w);
-            nd.ref = make_uint4(__float_as_uint(w3.x), __float_as_uint(w3.y), __float_as_uint(w3.z), __float_as_uint(w3.w));
-#define OT_DEQ(word, k, s_, o_) fmaf((float)(((word) >> (8 * (k))) & 255u), (s_), (o_))
-            nd.lx = make_float4(OT_DEQ(qlx, 0, w0.w, w0.x), OT_DEQ(qlx, 1, w0.w, w0.x), OT_DEQ(qlx, 2, w0.w, w0.x), OT_DEQ(qlx, 3, w0.w, w0.x));
-            nd.hx = make_float4(OT_DEQ(qhx, 0, w0.w, w0.x), OT_DEQ(qhx, 1, w0.w, w0.x), OT_DEQ(qhx, 2, w0.w, w0.x), OT_DEQ(qhx, 3, w0.w, w0.x));
-            nd.ly = make_float4(OT_DEQ(qly, 0, w1.x, w0.y), OT_DEQ(qly, 1, w1.x, w0.y), OT_DEQ(qly, 2, w1.x, w0.y), OT_DEQ(qly, 3, w1.x, w0.y));
-            nd.hy = make_float4(OT_DEQ(qhy, 0, w1.x, w0.y), OT_DEQ(qhy, 1, w1.x, w0.y), OT_DEQ(qhy, 2, w1.x, w0.y), OT_DEQ(qhy, 3, w1.x, w0.y));
-            nd.lz = make_float4(OT_DEQ(qlz, 0, w1.y, w0.z), OT_DEQ(qlz, 1, w1.y, w0.z), OT_DEQ(qlz, 2, w1.y, w0.z), OT_DEQ(qlz, 3, w1.y, w0.z));
-            nd.hz = make_float4(OT_DEQ(qhz, 0, w1.y, w0.z), OT_DEQ(qhz, 1, w1.y, w0.z), OT_DEQ(qhz, 2, w1.y, w0.z), OT_DEQ(qhz, 3, w1.y, w0.z));
-#undef OT_DEQ
-            // an empty child slot: both x planes at +inf, as in the float form (no walked ray enters it)
-            const float inf = __uint_as_float(0x7F800000u);
-            if (nd.ref.x == 0xFFFFFFFFu) nd.lx.x = nd.hx.x = inf;
-            if (nd.ref.y == 0xFFFFFFFFu) nd.lx.y = nd.hx.y = inf;
-            if (nd.ref.z == 0xFFFFFFFFu) nd.lx.z = nd.hx.z = inf;
-            if (nd.ref.w == 0xFFFFFFFFu) nd.lx.w = nd.hx.w = inf;
-            return nd;
-        }
-#else
         const float4* q = ac.nodes + MPT_OT_NODE_STRIDE * (size_t)n;
         nd.lx = q[0];
         nd.ly = q[1];
@@ -341,28 +277,7 @@ __device__ __forceinline__ OtNode ot_load_node(const AccelDev& ac, LdsNodes lds,
         nd.hz = q[5];
         const float4 g = q[6];
         nd.ref = make_uint4(__float_as_uint(g.x), __float_as_uint(g.y), __float_as_uint(g.z), __float_as_uint(g.w));
-#endif
-#if defined(MPT_OT_DIAG_DUP) && !MPT_OT_QNODES   // sensitivity experiment: 3 (or 7) more 16-byte loads of the same node (vector-L1 hits: tag look-ups only), one wait
-        {
-            v4f x0, x1, x2;
-            asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx4 %2, %3, off offset:32\n\t"
-#if MPT_OT_DIAG_DUP > 3
-                         "global_load_dwordx4 %0, %3, off offset:48\n\tglobal_load_dwordx4 %1, %3, off offset:64\n\tglobal_load_dwordx4 %2, %3, off offset:80\n\t"
-                         "global_load_dwordx4 %0, %3, off offset:96\n\t"
-#endif
-                         "s_waitcnt vmcnt(0)" : "=&v"(x0), "=&v"(x1), "=&v"(x2) : "v"(q) : "memory");
-            asm volatile("" ::"v"(x0), "v"(x1), "v"(x2));
-        }
-#endif
     }
-#ifdef MPT_OT_DIAG_VALU  // sensitivity experiment: MPT_OT_DIAG_VALU more vector instructions per node visit
-    {
-        float x = nd.lx.x;
-#pragma unroll
-        for (int k = 0; k < MPT_OT_DIAG_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));
-        asm volatile("" ::"v"(x));
-    }
-#endif
     return nd;
 }
 #endif
@@ -486,10 +401,30 @@ __device__ __forceinline__ uint32_t ot_pick(const uint4& ref, uint32_t key) {  /
     const uint32_t a = odd ? ref.y : ref.x, b = odd ? ref.w : ref.z;
     return high ? b : a;
 }
+// Round 5, two changes that take dependent LDS round trips and exec-mask bookkeeping out of a walk trip (MPT_OT_STACK2, measured on
+// bunny x20 with the diagnostics build: a wave-level pop made 1.95 trips of its loop — one LDS round trip each — and 78 % of all
+// node / leaf trips end in one):
+//  * the push is branch-free when three entries fit: the keys are sorted and hits come first, so the three children are written
+//    farthest first at sp, sp + [k3 hit], sp + [k3 hit] + [k2 hit] — an entry that is not a hit is overwritten by the next write
+//    or stays above the new top, where nothing reads it (three unconditional ds_write_b64 instead of three predicated regions);
+//  * the pop reads the TWO topmost entries with one instruction (entries of a lane are 512 bytes apart: ds_read2st64_b64).
+#ifndef MPT_OT_STACK2
+#define MPT_OT_STACK2 1
+#endif
 __device__ __forceinline__ void ot_push_sorted(const OtStack& st, uint32_t& sp, const uint4& ref, uint32_t k1, uint32_t k2,
                                                uint32_t k3, bool& lost) {
     const uint32_t room = st.depth - sp;
     const bool h1 = k1 < MPT_OT_KEY_MISS, h2 = k2 < MPT_OT_KEY_MISS, h3 = k3 < MPT_OT_KEY_MISS;
+#if MPT_OT_STACK2
+    if (room >= 3u) {   // (nearly always: the stack is 8 deep)
+        const uint32_t p2 = sp + (h3 ? 1u : 0u), p1 = p2 + (h2 ? 1u : 0u);
+        st.lds[sp * 64u] = v2u{k3, ot_pick(ref, k3)};
+        st.lds[p2 * 64u] = v2u{k2, ot_pick(ref, k2)};
+        st.lds[p1 * 64u] = v2u{k1, ot_pick(ref, k1)};
+        sp = p1 + (h1 ? 1u : 0u);
+        return;
+    }
+#endif
     if (h3 && room >= 3u) st.lds[sp++ * 64u] = v2u{k3, ot_pick(ref, k3)};
     if (h2 && room >= 2u) st.lds[sp++ * 64u] = v2u{k2, ot_pick(ref, k2)};
     if (h1 && room >= 1u) st.lds[sp++ * 64u] = v2u{k1, ot_pick(ref, k1)};
@@ -500,6 +435,28 @@ __device__ __forceinline__ uint32_t ot_pop_next(const OtStack& st, uint32_t& sp,
     wc.ot_pops++;
     if (first_active_lane()) wc.ot_pop_calls++;
 #endif
+#if MPT_OT_STACK2
+    while (sp > 0u) {
+        // entries sp - 2 and sp - 1 (with one entry left: 0 and 1, of which 1 is stale and not looked at)
+        const uint32_t b = (sp > 2u ? sp : 2u) - 2u;
+        const v2u lo = st.lds[b * 64u], hi = st.lds[(b + 1u) * 64u];
+#ifdef MPT_OT_TIMES
+        wc.ot_pop_iters++;
+        if (first_active_lane()) wc.ot_pop_wave_iters++;
+#endif
+        const bool two = sp >= 2u;
+        const v2u top = two ? hi : lo, below = lo;
+        if (__uint_as_float(top.x & ~3u) <= lim) {
+            sp -= 1u;
+            return top.y;
+        }
+        if (two && __uint_as_float(below.x & ~3u) <= lim) {
+            sp -= 2u;
+            return below.y;
+        }
+        sp = two ? sp - 2u : 0u;
+    }
+#else
     while (sp > 0u) {
         --sp;
         const v2u e = st.lds[sp * 64u];
@@ -509,6 +466,7 @@ __device__ __forceinline__ uint32_t ot_pop_next(const OtStack& st, uint32_t& sp,
 #endif
         if (__uint_as_float(e.x & ~3u) <= lim) return e.y;
     }
+#endif
     (void)wc;
     return MPT_OT_DONE;
 }
@@ -522,9 +480,6 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                                         const OtRay& r, uint32_t& cur, uint32_t& sp, float& T, int& W, bool& tie,
                                         bool& overflow, uint32_t budget, uint32_t min_active, WorkCount& wc) {
     uint32_t trips = 0;
-#ifdef MPT_OT_TOUCH
-    float touch = 0.0f;
-#endif
 #ifdef MPT_OT_TIMES
     unsigned long long wt_ = __builtin_amdgcn_s_memtime();
 #define OT_WTOC(field)                                                \
@@ -582,15 +537,11 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             } else {
                 cur = ot_pop_next(st, sp, lim, wc);
             }
-#ifdef MPT_OT_TOUCH   // (experiment) a lane that has just found its leaf touches the leaf's first primitive: the line is on its way while the others search
-            if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF && (cur & 0x07FFFFFFu) >= sc.n_lds_prims) touch = sc.prims[3u * (size_t)(cur & 0x07FFFFFFu)].x;
-#endif
         }
         OT_WTOC(ot_node_cycles);
         if (cur != MPT_OT_DONE && cur >= MPT_OT_LEAF) {  // a leaf: primitives [first, first + count) in index order
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
             if (COUNT && first_active_lane()) wc.outer_iters++;
-#if MPT_OT_LEAF2
             // The first two primitives of the leaf are loaded TOGETHER (one memory round trip, not two: the walk is a chain of
             // latencies, and the big scenes' leaves hold at most two), then tested in index order as before.
             uint32_t k_from = 0u;
@@ -624,18 +575,7 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
                 k_from = 2u;
             }
             for (uint32_t k = k_from; k < count; ++k) {
-#else
-#ifdef MPT_OT_PREFETCH   // loading primitive k + 1 while k is tested: measured slower (12 more VGPRs live: 28.7 vs 28.1 ms)
-            Prim3 nxt = load_prim(sc, lds, first);
-#endif
-            for (uint32_t k = 0; k < count; ++k) {
-#endif
-#ifdef MPT_OT_PREFETCH
-                const Prim3 pr = nxt;
-                if (k + 1u < count) nxt = load_prim(sc, lds, first + k + 1u);
-#else
                 const Prim3 pr = load_prim(sc, lds, first + k);
-#endif
                 if (COUNT) {
                     if (first_active_lane()) wc.prim_iters++;
                 }
@@ -652,9 +592,6 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
             cur = ot_pop_next(st, sp, ot_cull_limit(T, ac), wc);
         }
         OT_WTOC(ot_leaf_cycles);
-#ifdef MPT_OT_TOUCH
-        asm volatile("" ::"v"(touch));
-#endif
         const unsigned long long going = __ballot(cur != MPT_OT_DONE && (!BUDGETED || trips < budget));
         if (going == 0ull) break;
         if (BUDGETED && (uint32_t)__popcll(going) < min_active) break;
@@ -669,25 +606,10 @@ __device__ __forceinline__ bool ot_walk(const AccelDev& ac, const SceneDev& sc, 
 // skipped — they are needed only for winners within that bound of their box (hits on the ground sphere next to the origin).
 __device__ __forceinline__ bool ot_final_check(const AccelDev& ac, const SceneDev& sc, LdsNodes lds, F3 o, F3 d, const OtRay& r,
                                                float T, int W) {
-#if MPT_OT_REFBOX
     // the box of the winner's reference leaf, by primitive: two loads, one round trip (sc, lds: not needed)
     const float4 n0 = ac.refbox[2u * (size_t)(uint32_t)W], n1 = ac.refbox[2u * (size_t)(uint32_t)W + 1u];
     (void)sc;
     (void)lds;
-#else
-    const Prim3 pr = load_prim(sc, lds, (uint32_t)W);
-    float4 n0, n1;
-    if (ac.n_always != 0u && prim_type(pr.p0) == 0) {  // a sphere of the always list: its leaf box is in LDS
-        const LdsNodes q = lds + ac.lds_always_off + 5u * (uint32_t)__float_as_int(pr.p1.z) + 3u;
-        const v4f a = q[0], b = q[1];
-        n0 = make_float4(a.x, a.y, a.z, 0.0f);
-        n1 = make_float4(b.x, b.y, b.z, 0.0f);
-    } else {
-        const uint32_t leaf = prim_ref_leaf(pr.p0);
-        n0 = ac.refleaf[2u * (size_t)leaf];
-        n1 = ac.refleaf[2u * (size_t)leaf + 1u];
-    }
-#endif
     {
         float t0 = fmaf(n0.x, r.idx, -r.ox), t1 = fmaf(n1.x, r.idx, -r.ox);
         float lo = fminf(t0, t1), hi = fmaxf(t0, t1), m = fmaxf(fabsf(t0), fabsf(t1));
@@ -752,75 +674,6 @@ __device__ __forceinline__ void closest_hit_ordered(const AccelDev& ac, const Sc
     }
 }
 
-// 112-byte float nodes -> 64-byte nodes (see AccelDev).  One thread per node; runs once per scene (mpt_upload_scene, mpt_build_and_upload).
-__global__ void k_quantize_nodes(const float4* nodes, uint32_t n_nodes, float4* qnodes, uint32_t* n_float /* nodes whose boxes could not be quantised */) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    const float4* q = nodes + MPT_OT_NODE_STRIDE * (size_t)i;
-    float lo[3][4], hi[3][4];
-    uint32_t ref[4];
-    {
-        const float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
-        const float L[3][4] = {{a.x, a.y, a.z, a.w}, {b.x, b.y, b.z, b.w}, {c.x, c.y, c.z, c.w}};
-        const float H[3][4] = {{d.x, d.y, d.z, d.w}, {e.x, e.y, e.z, e.w}, {f.x, f.y, f.z, f.w}};
-        for (int ax = 0; ax < 3; ++ax)
-            for (int j = 0; j < 4; ++j) lo[ax][j] = L[ax][j], hi[ax][j] = H[ax][j];
-        ref[0] = __float_as_uint(g.x), ref[1] = __float_as_uint(g.y), ref[2] = __float_as_uint(g.z), ref[3] = __float_as_uint(g.w);
-    }
-    bool ok = true;
-    float o[3] = {0.0f, 0.0f, 0.0f}, s[3] = {1.0f, 1.0f, 1.0f};
-    uint32_t ql[3] = {0u, 0u, 0u}, qh[3] = {0u, 0u, 0u};
-    for (int ax = 0; ax < 3; ++ax) {
-        float mn = INFINITY, mx = -INFINITY;
-        for (int j = 0; j < 4; ++j) {
-            if (ref[j] == 0xFFFFFFFFu) continue;
-            if (!(isfinite(lo[ax][j]) && isfinite(hi[ax][j]) && lo[ax][j] <= hi[ax][j])) ok = false;
-            mn = fminf(mn, lo[ax][j]);
-            mx = fmaxf(mx, hi[ax][j]);
-        }
-        if (!(mn <= mx)) {   // no child at all (cannot happen) or nothing finite
-            ok = false;
-            mn = mx = 0.0f;
-        }
-        float sc = (mx - mn) / 255.0f;
-        if (!(sc > 1e-30f)) sc = 1e-30f;
-        for (int k = 0; k < 64 && fmaf(255.0f, sc, mn) < mx; ++k) sc = nextafterf(sc, INFINITY);
-        if (!isfinite(sc) || !isfinite(fmaf(255.0f, sc, mn)) || fmaf(255.0f, sc, mn) < mx) ok = false;
-        o[ax] = mn;
-        s[ax] = sc;
-        for (int j = 0; j < 4; ++j) {
-            uint32_t a = 255u, b = 0u;   // an empty slot: decoded planes are overwritten with +inf by the walk
-            if (ref[j] != 0xFFFFFFFFu && ok) {
-                float fa = floorf((lo[ax][j] - mn) / sc), fb = ceilf((hi[ax][j] - mn) / sc);
-                fa = fminf(fmaxf(fa, 0.0f), 255.0f);
-                fb = fminf(fmaxf(fb, 0.0f), 255.0f);
-                a = (uint32_t)fa;
-                b = (uint32_t)fb;
-                while (a > 0u && fmaf((float)a, sc, mn) > lo[ax][j]) --a;      // the decoded plane, in the walk's own arithmetic,
-                while (b < 255u && fmaf((float)b, sc, mn) < hi[ax][j]) ++b;    // must not cut into the float box
-                if (fmaf((float)a, sc, mn) > lo[ax][j] || fmaf((float)b, sc, mn) < hi[ax][j]) ok = false;
-            }
-            ql[ax] |= a << (8 * j);
-            qh[ax] |= b << (8 * j);
-        }
-    }
-    float4* out = qnodes + 4u * (size_t)i;
-    if (!ok) {   // a plane that is not finite, or an extent that overflows (degenerate input): boxes from -2.5e38 to +2.5e38 on every axis —
-                 // every ray enters every child, whose own node or primitives are then tested as always (conservative; counted)
-        atomicAdd(n_float, 1u);
-        for (int ax = 0; ax < 3; ++ax) {
-            o[ax] = -2.5e38f;
-            s[ax] = 1.9607843e36f;   // (5e38 / 255)
-            ql[ax] = 0u;
-            qh[ax] = 0xFFFFFFFFu;
-        }
-    }
-    out[0] = make_float4(o[0], o[1], o[2], s[0]);
-    out[1] = make_float4(s[1], s[2], __uint_as_float(ql[0]), __uint_as_float(ql[1]));
-    out[2] = make_float4(__uint_as_float(ql[2]), __uint_as_float(qh[0]), __uint_as_float(qh[1]), __uint_as_float(qh[2]));
-    out[3] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
-}
-
 __device__ __forceinline__ void ot_stage(const SceneDev& sc, const AccelDev& ac, float4* lds) {
     const uint32_t n4 = ac.n_lds_nodes * 7u, p4 = sc.n_lds_prims * 3u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {  // 7 of a node's MPT_OT_NODE_STRIDE float4 (the rest is padding)
@@ -841,20 +694,12 @@ __device__ __forceinline__ OtStack ot_stack(const AccelDev& ac, float4* lds_raw,
     return st;
 }
 
-// A ring record is read once: -DMPT_OT_NT_POP makes the pops non-temporal loads, so that they do not displace nodes and
-// primitives from the vector L1.  MEASURED AND REJECTED (round 4): bunny x20 67.9 ms against 64.3.
-__device__ __forceinline__ float4 ot_pop4(const float4* p) {
-#ifdef MPT_OT_NT_POP
-    const v4f_nt v = __builtin_nontemporal_load((const v4f_nt*)p);
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ uint4 ot_pop4u(const uint4* p) {
-    const float4 v = ot_pop4((const float4*)p);
-    return make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
-}
+// ring records: plain loads and stores (non-temporal pops lost 5 % in round 4, non-temporal pushes 11 % in round 5: a record is
+// popped a step or two after it was pushed and must still be in the L2 — tests/experiments/rejected_r05.h)
+__device__ __forceinline__ float4 ot_pop4(const float4* p) { return *p; }
+__device__ __forceinline__ uint4 ot_pop4u(const uint4* p) { return *p; }
+__device__ __forceinline__ void ot_put4(float4* p, const float4& v) { *p = v; }
+__device__ __forceinline__ void ot_put4u(uint4* p, const uint4& v) { *p = v; }
 
 // ---- the pipeline kernel ------------------------------------------------------------------------------------------
 #define MPT_OT_RING_R 0u                  // R0 ... R(NR-1)
@@ -1062,7 +907,6 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         }
         // the rest of a record is not needed by the tree walk: ring M steps load it afterwards
         auto load_rest = [&]() {
-#if MPT_OT_HITRING   // ia = (thr.b bits, path, t bits | light flag in the sign bit, primitive | bounce << 27): t / primitive = the hit of a ring-R record
             const uint4 ia = ot_pop4u(ring.ia() + at);
             ps.thr.z = __uint_as_float(ia.x);
             ps.path = ia.y;
@@ -1079,36 +923,10 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 ps.La = cc.w;
             }
             return;
-#elif MPT_WL_DIET   // the 48 + 16-byte record of mpt_kernels.h (WaveRings): tl only for the rays that have gathered light
-            const uint4 ia = ot_pop4u(ring.ia() + at);
-            ps.thr.z = __uint_as_float(ia.x);
-            ps.path = ia.y;
-            g.pixel = ia.z;
-            ps.bounce = ia.w & 0xFFu;
-            g.sample = sample_of_path(pp, ps.path);
-            ps.L = f3(0.0f, 0.0f, 0.0f);
-            ps.La = 0.0f;
-            if ((ia.w & MPT_RING_HAS_LIGHT) != 0u) {
-                const float4 cc = ot_pop4(ring.tl() + at);
-                ps.L = f3(cc.x, cc.y, cc.z);
-                ps.La = cc.w;
-            }
-#else
-            const float4 cc = ot_pop4(ring.tl() + at);
-            const uint4 ia = ot_pop4u(ring.ia() + at);
-            ps.thr.z = cc.x;
-            ps.L = f3(cc.y, cc.z, cc.w);
-            ps.La = __uint_as_float(ia.y);
-            ps.path = ia.x;
-            ps.bounce = ia.w >> 27;
-            g.pixel = ia.z;
-            g.sample = ia.w & 0x07FFFFFFu;
-#endif
             g.lit_seed = 0;
             if (pp.sp.rng_mode == 0) g.lit_seed = pcg_hash(pcg_hash(pp.pixel_seed[g.pixel]));
         };
         if (valid && kind != MPT_OT_NONE && kind < MPT_OT_RING_M) load_rest();
-#if MPT_OT_HITRING
         // ---- the hits popped from ring R are shaded first — all 64 lanes of the step — and leave their bounce rays in `ps` ------------
         if (valid && kind != MPT_OT_NONE && kind < MPT_OT_RING_E) {
             uint32_t px, py, sidx;
@@ -1124,7 +942,6 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
             T = INFINITY;
             W = -1;
         }
-#endif
         OT_TOC(1);
 #ifdef MPT_OT_TIMES
         const uint32_t ot_slot = kind == MPT_OT_NONE ? 2u + MPT_OT_MLEVELS : kind < MPT_OT_RING_E ? 0u : kind - MPT_OT_RING_E + 1u;
@@ -1211,18 +1028,12 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
         // ---- one bounce of shading for the rays whose closest hit is final ----------------------------------------------
         if (shade) {
             n_rays++;
-#if MPT_OT_HITRING
             if (W >= 0) {
                 dest = MPT_OT_RING_R;    // the hit, as it is: shaded by the step that pops it
             } else {                     // the sky ends the path (PathTracing.h:225-232)
                 shade_bounce(pp.scene, lds, pp.sp, g, ps, T, -1);
                 store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
             }
-#else
-            if (shade_bounce(pp.scene, lds, pp.sp, g, ps, T, W))
-                dest = MPT_OT_RING_R + (MPT_OT_NR > 1u ? (ps.d.x < 0.0f ? 1u : 0u) | (ps.d.y < 0.0f ? 2u : 0u) | (ps.d.z < 0.0f ? 4u : 0u) : 0u);
-            else store_slot(pp.slots, ps.path, clamp01(ps.L.x), clamp01(ps.L.y), clamp01(ps.L.z), clamp01(ps.La));
-#endif
         }
         n_flagged += dest == MPT_OT_RING_E ? 1u : 0u;
         n_parked += dest != MPT_OT_NONE && dest >= MPT_OT_RING_M ? 1u : 0u;
@@ -1237,35 +1048,24 @@ __global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassPa
                 cnt[k] += (uint32_t)__popcll(m);
             }
             if (dest != MPT_OT_NONE) {
-                ring.od()[to] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-                ring.dt()[to] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
-#if MPT_OT_HITRING
+                ot_put4(ring.od() + to, make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x));
+                ot_put4(ring.dt() + to, make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y));
                 {
                     const bool lit = ring_has_light(ps);
-                    ring.ia()[to] = make_uint4(__float_as_uint(ps.thr.z), ps.path, (__float_as_uint(T) & 0x7FFFFFFFu) | (lit ? 0x80000000u : 0u),
-                                               ((uint32_t)W & 0x07FFFFFFu) | (ps.bounce << 27));
-                    if (lit) ring.tl()[to] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
+                    ot_put4u(ring.ia() + to, make_uint4(__float_as_uint(ps.thr.z), ps.path, (__float_as_uint(T) & 0x7FFFFFFFu) | (lit ? 0x80000000u : 0u),
+                                                      ((uint32_t)W & 0x07FFFFFFu) | (ps.bounce << 27)));
+                    if (lit) ot_put4(ring.tl() + to, make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La));
                 }
-#elif MPT_WL_DIET
-                {
-                    const bool lit = ring_has_light(ps);
-                    ring.ia()[to] = make_uint4(__float_as_uint(ps.thr.z), ps.path, g.pixel, ps.bounce | (lit ? MPT_RING_HAS_LIGHT : 0u));
-                    if (lit) ring.tl()[to] = make_float4(ps.L.x, ps.L.y, ps.L.z, ps.La);
-                }
-#else
-                ring.tl()[to] = make_float4(ps.thr.z, ps.L.x, ps.L.y, ps.L.z);
-                ring.ia()[to] = make_uint4(ps.path, __float_as_uint(ps.La), g.pixel, g.sample | (ps.bounce << 27));
-#endif
                 if (dest >= MPT_OT_RING_M) {
                     // a ray parked by a top test starts its walk at the root (walk_cur = 0, walk_sp = 0 there)
-                    ring.tv()[to] = make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,
-                                             walk_sp | (walk_lost ? 0x40000000u : 0u) | (walk_again ? 0x80000000u : 0u));
+                    ot_put4u(ring.tv() + to, make_uint4(__float_as_uint(T), (uint32_t)W, walk_cur,
+                                                      walk_sp | (walk_lost ? 0x40000000u : 0u) | (walk_again ? 0x80000000u : 0u)));
                     if (walk_kind != MPT_OT_NONE) {   // (walk_sp = 0 for a ray that has not started)
 #pragma unroll
                         for (uint32_t k = 0; k < MPT_OT_PARK / 2u; ++k) {
                             if (walk_sp > 2u * k) {
                                 const v2u e0 = st.lds[(2u * k) * 64u], e1 = st.lds[(2u * k + 1u) * 64u];
-                                ring.sk(k)[to] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+                                ot_put4u(ring.sk(k) + to, make_uint4(e0.x, e0.y, e1.x, e1.y));
                             }
                         }
                     }

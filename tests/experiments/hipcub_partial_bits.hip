@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <numeric>
 #include <random>
+#include <string>
 #include <vector>
 
 #define CHK(x)                                                                          \
@@ -84,8 +85,29 @@ static int run_case(const char* what, const std::vector<K>& keys, int begin_bit,
         bad_in += in_after[i] != keys[i];
     }
     for (size_t i = 0; i < CANARY; ++i) bad_canary += (c0[i] != 0xA5) + (c1[i] != 0xA5) + (c2[i] != 0xA5);
+    // what IS the output sorted by, when it is not what was asked for?  (inversions of neighbours under a few readings of the arguments)
+    std::string sorted_by;
+    if (bad_keys) {
+        struct View { const char* name; int b, e; } views[] = {{"[begin,end)", begin_bit, end_bit}, {"[0,end-begin)", 0, end_bit - begin_bit}, {"[0,end)", 0, end_bit},
+                                                                {"[begin,begin+8)", begin_bit, begin_bit + 8}, {"[0,8*sizeof)", 0, (int)(8 * sizeof(K))}};
+        for (const View& v : views) {
+            const int nb = v.e - v.b;
+            const K m = nb >= (int)(8 * sizeof(K)) ? ~(K)0 : (K)((((K)1) << nb) - 1);
+            size_t inv = 0;
+            for (size_t i = 1; i < n; ++i) inv += ((ok[i - 1] >> v.b) & m) > ((ok[i] >> v.b) & m);
+            char buf[96];
+            snprintf(buf, sizeof buf, " %s:%zu", v.name, inv);
+            sorted_by += buf;
+        }
+        // is it a permutation of the input at all?
+        std::vector<K> a(keys), b2(ok);
+        std::sort(a.begin(), a.end());
+        std::sort(b2.begin(), b2.end());
+        sorted_by += a == b2 ? " (a permutation of the input)" : " (NOT a permutation of the input)";
+    }
     printf("%-34s n %8zu bits [%2d,%2d) temp %9zu B: values wrong %zu, keys wrong %zu, input changed %zu, canary bytes overwritten %zu  %s\n", what, n, begin_bit,
            end_bit, bytes, bad_vals, bad_keys, bad_in, bad_canary, bad_vals + bad_keys + bad_in + bad_canary ? "FAIL" : "ok");
+    if (!sorted_by.empty()) printf("    inversions of neighbouring output keys when read on bits%s\n", sorted_by.c_str());
     hipFree(dk);
     hipFree(dk2);
     hipFree(dv);

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 from oracle import binding as ob
-from test_gpu_parity import setup
+from test_gpu_parity import setup, setup_tree
 
 pytestmark = pytest.mark.gpu
 
