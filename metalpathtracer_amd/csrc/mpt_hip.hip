@@ -142,7 +142,14 @@ struct mpt_ctx {
     float4* d_refleaf = nullptr;
     float4* d_refbox = nullptr;       // the box of its reference leaf PER PRIMITIVE, 2 float4 each: the final check of the closest-first walk needs no look-up through the primitive
     float4* d_always = nullptr;
-    uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, ot_lds_nodes = 0, ot_lds_prims = 0;
+    uint32_t n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0;
+    // the two operating points of the closest-first kernel (mpt_ordered.h: k_ordered<.., 5> = 5 x 256 threads per CU, k_ordered<.., 6> = 2 x 768) and
+    // what each stages in LDS for the scene at hand (size_lds_images)
+    struct OtPoint {
+        uint32_t threads, wgs_per_cu, lds_nodes, lds_prims;
+    } ot_pt[2] = {{MPT_OT_THREADS, MPT_OT_WGS_PER_CU, 0, 0}, {MPT_OT6_THREADS, (MPT_OT6_WAVES * 256) / MPT_OT6_THREADS, 0, 0}};
+    int ot_occ = 0;                  // MPT_OT_OCC: 5 / 6 forces an operating point, 0 = by scene size (ordered_point)
+    bool tile_order_forced = false;  // MPT_TILE_ORDER was given
     // mpt_build_and_upload keeps its tree in the reference's buffer format on the device too (mpt_download_bvh)
     float4* d_ref_bvh = nullptr;
     int* d_ref_idx = nullptr;
@@ -165,6 +172,7 @@ struct mpt_ctx {
     // this rank's tile processing order (x | y << 16), rebuilt when size or sharding changes
     uint32_t* d_tile_xy = nullptr;
     uint32_t tile_W = 0, tile_H = 0, tile_rank = 0, tile_nranks = 0, tile_count = 0;
+    int tile_mode_built = -1;   // tile order the table was built for (tile_order_of)
     int tile_order_mode = 0;  // 0 row-major top-down (measured best with guided claims: the cheap sky tiles take the
                               // large early claims, the expensive tiles the small late ones), 1 strided, 2 bottom-up
     // literal RNG seeds
@@ -202,7 +210,8 @@ static const void* mega_kernel(bool count, bool all_lds) {
     return all_lds ? (const void*)k_megakernel<false, true> : (const void*)k_megakernel<false, false>;
 }
 
-static const void* ordered_kernel(bool count, bool all_lds) {
+static const void* ordered_kernel(bool count, bool all_lds, bool six = false) {
+    if (six && !count) return all_lds ? (const void*)k_ordered<false, true, MPT_OT6_WAVES> : (const void*)k_ordered<false, false, MPT_OT6_WAVES>;
     if (count) return all_lds ? (const void*)k_ordered<true, true> : (const void*)k_ordered<true, false>;
     return all_lds ? (const void*)k_ordered<false, true> : (const void*)k_ordered<false, false>;
 }
@@ -329,7 +338,11 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
         for (uint32_t k = 0; k + 1 < MPT_WL_LEVELS; ++k) ctx->budgets.b[k] = b > (1u << 28) ? b : std::min<uint64_t>((uint64_t)b << k, MPT_WL_NO_BUDGET);
     }
     if ((e = getenv("MPT_WL_MIN")) && atoi(e) >= 64) ctx->wl_min = (uint32_t)atoi(e) & ~63u;
-    if ((e = getenv("MPT_TILE_ORDER"))) ctx->tile_order_mode = atoi(e);
+    if ((e = getenv("MPT_TILE_ORDER"))) {
+        ctx->tile_order_mode = atoi(e);
+        ctx->tile_order_forced = true;
+    }
+    if ((e = getenv("MPT_OT_OCC")) && (atoi(e) == 5 || atoi(e) == 6)) ctx->ot_occ = atoi(e);
     if ((e = getenv("MPT_WL_DIV")) && atoi(e) >= 1) ctx->wl_div = (uint32_t)atoi(e);
     if ((e = getenv("MPT_OT_STACK")) && atoi(e) >= 2 && atoi(e) <= (int)MPT_OT_PARK) ctx->ot_stack_depth = (uint32_t)atoi(e);
     for (int which = 0; which < 2; ++which)
@@ -358,7 +371,10 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
             if (!c) hipFuncSetAttribute(wavelocal_kernel(false, a, true), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
     for (int c = 0; c < 2; ++c)
-        for (int a = 0; a < 2; ++a) hipFuncSetAttribute(ordered_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int a = 0; a < 2; ++a) {
+            hipFuncSetAttribute(ordered_kernel(c, a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (!c) hipFuncSetAttribute(ordered_kernel(false, a, true), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
     hipFuncSetAttribute((const void*)k_trace_rays_ordered, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
@@ -453,21 +469,31 @@ static void size_lds_images(mpt_ctx* ctx) {
         ctx->n_lds_prims = (uint32_t)(prim_bytes / 48);
         ctx->n_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, (budget - prim_bytes) / 32);
     }
-    // LDS image of the closest-first kernel (MPT_OT_WGS_PER_CU workgroups of MPT_OT_THREADS share a CU's 160 KiB): the
-    // stacks, then as many own nodes as fit (breadth-first prefix), the always list, and primitives with what is left.
-    {
-        const size_t stacks = (size_t)MPT_OT_THREADS * ctx->ot_stack_depth * 8;
+    // LDS image of the closest-first kernel at each of its operating points (wgs_per_cu workgroups of `threads` share a CU's 160 KiB):
+    // the stacks, then as many own nodes as fit (breadth-first prefix), the always list, and primitives with what is left.
+    for (mpt_ctx::OtPoint& pt : ctx->ot_pt) {
+        const size_t stacks = (size_t)pt.threads * ctx->ot_stack_depth * 8;
         // (two workgroups per CU get 78 KiB each, not 80: the allocation granule must leave both room)
-        const size_t avail = MPT_OT_WGS_PER_CU == 1 ? 160 * 1024 : 156 * 1024 / MPT_OT_WGS_PER_CU, fixed = MPT_LDS_EXTRA + stacks + (size_t)ctx->n_always * 80;
+        const size_t avail = pt.wgs_per_cu == 1 ? 160 * 1024 : 156 * 1024 / pt.wgs_per_cu, fixed = MPT_LDS_EXTRA + stacks + (size_t)ctx->n_always * 80;
         const size_t total = avail > fixed + 112 ? avail - fixed : 112;
         const size_t all_nodes = (size_t)ctx->n_acc_nodes * 112, all_prims = (size_t)ctx->n_prims * 48;
         size_t prim_bytes = all_nodes <= total ? std::min(all_prims, total - all_nodes)
                                                : std::min<size_t>(all_prims, std::min<size_t>(4 * 1024, total / 4));
         if (const char* e = getenv("MPT_OT_LDS_PRIMS")) prim_bytes = std::min<size_t>(prim_bytes, (size_t)atoi(e) * 48);
         prim_bytes -= prim_bytes % 48;
-        ctx->ot_lds_prims = (uint32_t)(prim_bytes / 48);
-        ctx->ot_lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
+        pt.lds_prims = (uint32_t)(prim_bytes / 48);
+        pt.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_acc_nodes, (total - prim_bytes) / 112);
     }
+}
+// Which operating point of the closest-first kernel renders this scene: the six-wave one up to MPT_OT6_MAX_PRIMS primitives (the
+// sixth wave pays while a compute die's L2 can mostly hold the tree: 40 k / 99 k / 397 k primitives -2.5 .. -3.6 % with the striped
+// tile order; the 1 M-triangle scene of configs[4] +0.5 .. +7 % — mpt_ordered.h), the five-wave one beyond and for counted renders.
+#define MPT_OT6_MAX_PRIMS 600000u
+static int ordered_point(const mpt_ctx* ctx, bool count) {
+    if (count) return 0;
+    if (ctx->ot_occ == 5) return 0;
+    if (ctx->ot_occ == 6) return 1;
+    return ctx->n_prims <= MPT_OT6_MAX_PRIMS ? 1 : 0;
 }
 
 // the per-primitive reference-leaf boxes of an uploaded scene (k_prim_refbox, mpt_devbuild.h)
@@ -946,16 +972,18 @@ static SceneDev scene_dev(const mpt_ctx* ctx) {
 
 // The closest-first kernel's view: own nodes / always list / primitives / materials / stacks in LDS; the threaded
 // reference-order nodes stay in global memory (ring E and the test hook walk them from there).
-static size_t ordered_views(const mpt_ctx* ctx, uint32_t threads, uint32_t stack_depth, SceneDev& s, AccelDev& a) {
+static size_t ordered_views(const mpt_ctx* ctx, int point, uint32_t stack_depth, SceneDev& s, AccelDev& a) {
+    const mpt_ctx::OtPoint& pt = ctx->ot_pt[point];
+    const uint32_t threads = pt.threads;
     s = scene_dev(ctx);
     s.n_lds_nodes = 0;
-    s.n_lds_prims = ctx->ot_lds_prims;
+    s.n_lds_prims = pt.lds_prims;
     a.nodes = ctx->d_acc_nodes;
     a.refleaf = ctx->d_refleaf;
     a.refbox = ctx->d_refbox;
     a.always = ctx->d_always;
     a.n_nodes = ctx->n_acc_nodes;
-    a.n_lds_nodes = ctx->ot_lds_nodes;
+    a.n_lds_nodes = pt.lds_nodes;
     a.n_always = ctx->n_always;
     a.lds_always_off = 7u * a.n_lds_nodes;
     s.lds_prim_off = a.lds_always_off + 5u * a.n_always;
@@ -1009,15 +1037,15 @@ static int ensure_pixel_seeds(mpt_ctx* ctx) {
 
 // Tiles t with t % nranks == rank, in the order the pass walks them.  Strided order: local index k -> local tile
 // (k * P) mod n with P ~ 0.618 n coprime to n, which spreads consecutive path-id windows over the whole image.
-static int ensure_tile_order(mpt_ctx* ctx, uint32_t rank, uint32_t nranks, uint32_t& n_local) {
+static int ensure_tile_order(mpt_ctx* ctx, uint32_t rank, uint32_t nranks, int mode, uint32_t& n_local) {
     const uint32_t tiles_x = (ctx->W + 7) / 8, tiles_y = (ctx->H + 7) / 8, tiles = tiles_x * tiles_y;
     n_local = tiles > rank ? (tiles - rank + nranks - 1) / nranks : 0;
     if (ctx->d_tile_xy && ctx->tile_W == ctx->W && ctx->tile_H == ctx->H && ctx->tile_rank == rank &&
-        ctx->tile_nranks == nranks)
+        ctx->tile_nranks == nranks && ctx->tile_mode_built == mode)
         return MPT_OK;
     std::vector<uint32_t> xy(std::max<uint32_t>(n_local, 1));
     uint64_t P = 1;
-    if (ctx->tile_order_mode == 1 && n_local > 2) {
+    if (mode == 1 && n_local > 2) {
         P = (uint64_t)(0.6180339887 * n_local) | 1ull;
         auto gcd = [](uint64_t a, uint64_t b) {
             while (b) {
@@ -1031,11 +1059,11 @@ static int ensure_tile_order(mpt_ctx* ctx, uint32_t rank, uint32_t nranks, uint3
     }
     for (uint32_t k = 0; k < n_local; ++k) {
         uint32_t tl = (uint32_t)(((uint64_t)k * P) % n_local);
-        if (ctx->tile_order_mode == 2) tl = n_local - 1u - k;  // bottom-up row-major
+        if (mode == 2) tl = n_local - 1u - k;  // bottom-up row-major
         const uint32_t T = tl * nranks + rank;
         xy[k] = (T % tiles_x) | ((T / tiles_x) << 16);
     }
-    if (ctx->tile_order_mode == 3 && n_local >= MPT_NGROUP) {
+    if (mode == 3 && n_local >= MPT_NGROUP) {
         // XCD stripes (round 5): claim range g — the workgroups with blockIdx % 8 == g, one XCD under round-robin placement, with an L2
         // of its own — owns the tiles at positions k % 8 == g of this table (range_chunk_to_path_chunk).  Row-major order gives every
         // range every 8th tile of every row: all eight L2s see the whole scene.  Here the rank's tiles are cut into eight vertical
@@ -1066,6 +1094,7 @@ static int ensure_tile_order(mpt_ctx* ctx, uint32_t rank, uint32_t nranks, uint3
     ctx->tile_H = ctx->H;
     ctx->tile_rank = rank;
     ctx->tile_nranks = nranks;
+    ctx->tile_mode_built = mode;
     ctx->tile_count = n_local;
     return MPT_OK;
 }
@@ -1126,13 +1155,21 @@ static int resolve_pipeline(const mpt_ctx* ctx, int pipeline, int rng_mode = MPT
     return pipeline;
 }
 
+// The order in which a pass walks the rank's tiles: what MPT_TILE_ORDER says, else row-major — or, for the six-wave operating point of
+// the closest-first kernel, one vertical stripe of the image per claim range = per XCD (ensure_tile_order, mode 3: measured together).
+static int tile_order_of(const mpt_ctx* ctx, const mpt_render_params* p) {
+    if (ctx->tile_order_forced) return ctx->tile_order_mode;
+    return resolve_pipeline(ctx, p->pipeline, p->rng_mode) == MPT_PIPE_ORDERED && ordered_point(ctx, count_flag(p)) == 1 ? 3 : 0;
+}
+
 // Runs one pass of S samples/pixel over this rank's tiles; leaves the per-path results in d_slots.
 static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t sample_begin, uint32_t S, PassParams& pp,
                     uint32_t& n_local_tiles, bool time_kernels) {
     const uint32_t tiles_x = (ctx->W + 7) / 8;
     const uint32_t nr = (uint32_t)p->shard_count, rk = (uint32_t)p->shard_rank;
+    const int tile_mode = tile_order_of(ctx, p);
     {
-        int trc = ensure_tile_order(ctx, rk, nr, n_local_tiles);
+        int trc = ensure_tile_order(ctx, rk, nr, tile_mode, n_local_tiles);
         if (trc) return trc;
     }
     const uint64_t pass_paths = (uint64_t)n_local_tiles * S * 64ull;
@@ -1174,7 +1211,7 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
         // while T * tiles_x < 2^32 (error term T * (tiles_x - 1) / (tiles_x * 2^32) < 1 / tiles_x); otherwise the table
         const uint64_t tiles = (uint64_t)tiles_x * ((ctx->H + 7) / 8);
         pp.tile_magic = 0u;
-        if (ctx->tile_order_mode == 0 && tiles_x >= 2u && tiles * tiles_x < (1ull << 32) && getenv("MPT_TILE_TABLE") == nullptr)
+        if (tile_mode == 0 && tiles_x >= 2u && tiles * tiles_x < (1ull << 32) && getenv("MPT_TILE_TABLE") == nullptr)
             pp.tile_magic = (uint32_t)(((1ull << 32) + tiles_x - 1u) / tiles_x);
     }
     pp.sp.rng_mode = p->rng_mode;
@@ -1197,16 +1234,17 @@ static int run_pass(mpt_ctx* ctx, Lane& L, const mpt_render_params* p, uint32_t 
     // a render that overlaps others (mpt_render_async) runs the variant of the wave-local kernel that leaves room on the CU for the
     // resolve of the render before it (k_wavelocal_corun); only then may the end of one pass overlap the start of the next (below)
     const bool corun = (ctx->lane_order & 4) && !ctx->sync_render && pipeline == MPT_PIPE_WAVELOCAL && !count_flag(p);
+    const int ot_point = pipeline == MPT_PIPE_ORDERED ? ordered_point(ctx, count_flag(p)) : 0;
     const void* kfun = pipeline == MPT_PIPE_MEGAKERNEL ? mega_kernel(count_flag(p), all_lds)
                        : pipeline == MPT_PIPE_WAVELOCAL ? wavelocal_kernel(count_flag(p), all_lds, corun)
-                       : pipeline == MPT_PIPE_ORDERED  ? ordered_kernel(count_flag(p), ctx->ot_lds_nodes == ctx->n_acc_nodes)
+                       : pipeline == MPT_PIPE_ORDERED  ? ordered_kernel(count_flag(p), ctx->ot_pt[ot_point].lds_nodes == ctx->n_acc_nodes, ot_point == 1)
                                                         : step_kernel(count_flag(p), all_lds);
-    // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel, mpt_ordered.h: 1024)
-    const int wg_max = pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : 1024;
-    const int wg = pipeline == MPT_PIPE_ORDERED ? MPT_OT_THREADS : ctx->wg_size > 0 && ctx->wg_size <= wg_max ? ctx->wg_size : wg_max;
+    // workgroup size = the kernel's launch bound (mpt_kernels.h: 768 for the wave-local kernel; mpt_ordered.h: 256 or 768 by operating point)
+    const int wg_max = pipeline == MPT_PIPE_WAVELOCAL ? MPT_WL_THREADS(all_lds) : pipeline == MPT_PIPE_ORDERED ? (int)ctx->ot_pt[ot_point].threads : 1024;
+    const int wg = pipeline == MPT_PIPE_ORDERED ? wg_max : ctx->wg_size > 0 && ctx->wg_size <= wg_max ? ctx->wg_size : wg_max;
     AccelDev accel = {};
     if (pipeline == MPT_PIPE_ORDERED) {
-        lds = ordered_views(ctx, (uint32_t)wg, ctx->ot_stack_depth, pp.scene, accel);
+        lds = ordered_views(ctx, ot_point, ctx->ot_stack_depth, pp.scene, accel);
         if (!ordered_layout_ok(pp.scene, accel, (uint32_t)wg, lds)) return fail(ctx, MPT_ERR_INVALID_ARG, "LDS layout of the closest-first kernel overlaps (internal)");
     }
     if (ctx->occ_fun == kfun && ctx->occ_lds == lds) {
@@ -1458,7 +1496,7 @@ static int render_async_impl(mpt_ctx* ctx, const mpt_render_params* p) {
     HIPCHK(hipSetDevice(ctx->device));
     // a render with another size / sharding rebuilds the shared tile table: nothing may be in flight then
     if (ctx->d_tile_xy && (ctx->tile_W != ctx->W || ctx->tile_H != ctx->H || ctx->tile_rank != (uint32_t)p->shard_rank ||
-                           ctx->tile_nranks != (uint32_t)p->shard_count) &&
+                           ctx->tile_nranks != (uint32_t)p->shard_count || ctx->tile_mode_built != tile_order_of(ctx, p)) &&
         (rc = wait_impl(ctx)))
         return rc;
     Lane& L = ctx->lane[ctx->next_lane];
@@ -1639,7 +1677,7 @@ static int trace_rays_ordered_impl(mpt_ctx* ctx, const float* o, const float* d,
     HIPCHK(hipMemcpy(d_d.p, d, n * 12, hipMemcpyHostToDevice));
     SceneDev sc;
     AccelDev ac;
-    const size_t lds = ordered_views(ctx, 256, ctx->ot_stack_depth, sc, ac);
+    const size_t lds = ordered_views(ctx, 0, ctx->ot_stack_depth, sc, ac);   // (the five-wave operating point's image: workgroups of 256)
     if (!ordered_layout_ok(sc, ac, 256u, lds)) return fail(ctx, MPT_ERR_INVALID_ARG, "LDS layout of the closest-first kernel overlaps (internal)");
     hipLaunchKernelGGL(k_trace_rays_ordered, dim3(blocks), dim3(256), lds, ctx->stream, sc, ac, (const float*)d_o.p, (const float*)d_d.p,
                        (uint32_t)n, (float*)d_t.p, (int*)d_p.p, (float*)d_n.p, (int*)d_f.p, (uint32_t*)d_g.p);
@@ -2010,7 +2048,7 @@ extern "C" int mpt_trace_rays_ordered(mpt_ctx* ctx, const float* o, const float*
 extern "C" int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]) {
     if (!ctx || !out) return MPT_ERR_INVALID_ARG;
     if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
-    const uint64_t v[8] = {ctx->acc_ok ? 1u : 0u, ctx->n_acc_nodes, ctx->acc_depth, ctx->ot_lds_nodes, ctx->n_always, ctx->n_ref_leaves, ctx->ot_lds_prims,
+    const uint64_t v[8] = {ctx->acc_ok ? 1u : 0u, ctx->n_acc_nodes, ctx->acc_depth, ctx->ot_pt[ordered_point(ctx, false)].lds_nodes, ctx->n_always, ctx->n_ref_leaves, ctx->ot_pt[ordered_point(ctx, false)].lds_prims,
                            (uint64_t)resolve_pipeline(ctx, MPT_PIPE_AUTO)};
     memcpy(out, v, sizeof v);
     return MPT_OK;

@@ -711,9 +711,22 @@ __device__ __forceinline__ void ot_put4u(uint4* p, const uint4& v) { *p = v; }
 #define MPT_OT_MAX_INFLIGHT (MPT_WL_RING - 64u)
 #define MPT_OT_NONE 0xFFu
 
-template <bool COUNT, bool ALL_LDS>
-__global__ __launch_bounds__(MPT_OT_THREADS, MPT_OT_WAVES) void k_ordered(PassParams pp, AccelDev ac, OtRings ring, OtBudgets budgets,
-                                                                          uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
+// Two operating points of ONE body (round 5):
+//   k_ordered<.., 5>   five workgroups of 256 threads per CU = 5 waves/SIMD at 96 VGPRs, no scratch, ~100 nodes of the tree in each workgroup's LDS
+//   k_ordered<.., 6>   two workgroups of 768 per CU = 6 waves/SIMD at 80 VGPRs — the walk loops fit, 22-24 values of a step's bookkeeping
+//                are spilled around them (a few dwords of scratch per STEP, none per trip) — and ~270 nodes in LDS
+// Same-box A/B (gpurun_out/r05/s5-s8): the sixth wave wins on scenes whose tree a compute die's L2 can mostly hold and loses on
+// bigger ones, where one more wave per SIMD is one more stream of misses — 8 / 20 / 80 bunnies (40 k / 99 k / 397 k primitives):
+// -2.5 % / -1.0..-1.5 % / -0.6 %, with each claim range rendering a vertical stripe of the image (MPT_TILE_ORDER=3, mpt_hip.hip) -3.6 % /
+// -2.6 % / -2.7 %; the 1 M-triangle height fields of configs[4]: +0.5..+7 % SLOWER, with or without the stripes.  The host picks by
+// the scene's size (mpt_hip.hip: ordered_point; MPT_OT_OCC=5|6 forces one).
+#define MPT_OT6_THREADS 768
+#define MPT_OT6_WAVES 6
+// (one kernel template, the operating point in its launch bounds: a shared __forceinline__ body behind two __global__ wrappers cost the
+//  five-wave instantiation 4-18 spilled VGPRs — the by-reference / by-value copies of the argument structs changed the allocation)
+template <bool COUNT, bool ALL_LDS, int OCC = MPT_OT_WAVES>
+__global__ __launch_bounds__(OCC == MPT_OT6_WAVES ? MPT_OT6_THREADS : MPT_OT_THREADS, OCC) void k_ordered(PassParams pp, AccelDev ac, OtRings ring, OtBudgets budgets,
+                                                                                                         uint32_t wl_block, uint32_t wl_min, uint32_t wl_div) {
     extern __shared__ float4 lds_raw[];
     // camera and budgets live in LDS (the MPT_LDS_CFG_F4 block behind the material table), not in scalar registers across the step loop
     // (as in k_wavelocal, mpt_kernels.h)

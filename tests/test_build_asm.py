@@ -65,10 +65,29 @@ def test_handover_stores_are_drained_before_the_arrival_atomic(disassembly, kern
 
 
 def test_trace_kernels_hold_their_register_budget(disassembly):
-    """The operating points DESIGN.md states: k_wavelocal without scratch at 6 waves/SIMD (<= 80 VGPRs), k_ordered at 5 (<= 96).
+    """The operating points DESIGN.md states: k_wavelocal without scratch at 6 waves/SIMD (<= 80 VGPRs), k_ordered<.., 5> at 5 (<= 96).
     Read from the kernel descriptors' symbol table is not possible here; the instruction stream must not touch scratch."""
-    for key in ("k_wavelocalILb0ELb1E", "k_orderedILb0ELb0E", "k_orderedILb0ELb1E", "k_wavelocalILb0ELb0E"):
+    for key in ("k_wavelocalILb0ELb1E", "k_orderedILb0ELb0ELi5E", "k_orderedILb0ELb1ELi5E", "k_wavelocalILb0ELb0E"):
         names = [n for n in disassembly if key in n and n.startswith("_Z")]
         assert len(names) == 1, (key, names)
         scratch = [s for s in disassembly[names[0]] if s.startswith(("scratch_", "buffer_store_dword v", "buffer_load_dword v")) and "off" in s and "s[0:3]" in s]
         assert not [s for s in disassembly[names[0]] if s.startswith("scratch_")], (key, scratch[:4])
+
+
+def test_six_wave_closest_first_kernel_spills_around_its_walk_loops_not_inside(disassembly):
+    """k_ordered<.., 6> (2 x 768 threads per CU, 80 VGPRs: mpt_ordered.h) may spill a step's bookkeeping to scratch — a few dwords per
+    STEP — but the node loop of the walk, the hot code of the kernel, must stay free of scratch traffic: no scratch instruction within
+    the 30 instructions in front of a node fetch (seven 16-byte loads off the tree's base pointer in scalar registers) or the 260 behind it."""
+    for key in ("k_orderedILb0ELb0ELi6E",):
+        names = [n for n in disassembly if key in n and n.startswith("_Z")]
+        assert len(names) == 1, (key, names)
+        ins = disassembly[names[0]]
+        loads = [i for i, s in enumerate(ins) if s.startswith("global_load_dwordx4") and re.search(r"s\[\d+:\d+\]", s)]
+        fetches = [i for k, i in enumerate(loads) if k + 6 < len(loads) and loads[k + 6] - i <= 24]     # first load of a 7-load cluster
+        fetches = [i for k, i in enumerate(fetches) if k == 0 or i - fetches[k - 1] > 24]
+        assert len(fetches) >= 2, loads                      # (the budgeted and the unbudgeted instantiation of the walk)
+        scratch = [i for i, s in enumerate(ins) if s.startswith("scratch_")]
+        assert len(scratch) <= 80, len(scratch)
+        for f in fetches:
+            near = [i for i in scratch if f - 30 <= i <= f + 260]
+            assert not near, (key, f, [ins[i] for i in near][:4])

@@ -6,7 +6,7 @@ export SPP=${SPP:-256} PIPE=${PIPE:-4} BVH=${BVH:-3} REPS=${REPS:-5}
 for SCENE in ${SCENES:-scene.xml bunny20.xml}; do
   export SCENE
   for v in "$@"; do
-    n=${v%%:*}; e=${v#*:}; [ "$e" = "$v" ] && e=""; e=${e//,/ }   # (ENV entries may also be joined by commas)
+    n=${v%%:*}; e=${v#*:}; [ "$e" = "$v" ] && e=""; e=${e//+/ }   # (several ENV entries: joined by +)
     lib=$PWD/metalpathtracer_amd/lib/libmpt_hip_$n.so; [ "$n" = base ] && lib=$PWD/metalpathtracer_amd/lib/libmpt_hip.so
     [ -f "$lib" ] || { echo "$SCENE $n: $lib missing"; continue; }
     env MPT_LIB=$lib $e python3 tools/prof_run.py > /tmp/ab_$$.log 2>&1 || { echo "$SCENE $n [$e]: FAILED $(tail -1 /tmp/ab_$$.log)"; continue; }
