@@ -60,10 +60,17 @@ static WaveBudgets default_budgets() {
 // and the number of lanes that must still be walking for a step to go on (MPT_OT_MIN_ACTIVE).
 static OtBudgets default_ot_budgets() {
     OtBudgets b;
-    const uint32_t ladder[] = {16, 48, 120, 300, 750};  // measured on scene.xml / bunny x20: 4,10 -> 29.3 / 123 ms, 12,32 -> 28.1 / 113, 16,48 -> 27.4 / 111, 24,64 -> 28.4 / 115
+    // Round 5: a walk step of ring M0 (and a walk made in place by a top-test step) ends when fewer than 24 of its lanes still walk,
+    // or after 32 trips of the node loop; a step of the last ring when fewer than 32 do.  Until round 4 the first rule did not exist
+    // (16 trips and out, whoever was still walking): a trip budget cuts a step short while most of its lanes are still busy and sends
+    // them through a ring for nothing, a utilisation rule ends it when it has become wasteful.  Same-box sweep (gpurun_out/r05/s10, s11:
+    // budgets 16 .. 1000 x minimum lanes 0 .. 40 x 24 / 32), (16; 0, 24) -> (32; 24, 32): 8 / 20 bunnies 43.6 -> 42.8 / 55.1 -> 53.9 ms,
+    // the 1 M-triangle shard of configs[4] 117.2 -> 113.2; no trip budget at all (1000; 24, 32) is the same within 0.1 %; a budget
+    // WITHOUT the rule is far worse than before (32; 0, 24: 64.9 ms on bunny x20).  Rounds 2-3: 4,10 -> 29.3 / 123 ms, 16,48 -> 27.4 / 111.
+    const uint32_t ladder[] = {32, 96, 240, 600, 1500};
     for (uint32_t k = 0; k < MPT_OT_MLEVELS; ++k) {
         b.trips[k] = k + 1 < MPT_OT_MLEVELS && k < 5 ? ladder[k] : 0x7FFFFFFFu;
-        b.min_active[k] = k == 0 ? 0 : 24;
+        b.min_active[k] = k + 1 < MPT_OT_MLEVELS ? 24 : 32;
     }
     b.inplace_min = 48;   // bunny x20 256 spp: never 74.9 ms, 56 72.6, 48 72.8, 40 73.1, 32 73.7, 24 74.4; scene.xml 25.96 / 25.6 / 25.6 / 25.7 / 25.9 / 26.6
     return b;
@@ -486,9 +493,10 @@ static void size_lds_images(mpt_ctx* ctx) {
     }
 }
 // Which operating point of the closest-first kernel renders this scene: the six-wave one up to MPT_OT6_MAX_PRIMS primitives (the
-// sixth wave pays while a compute die's L2 can mostly hold the tree: 40 k / 99 k / 397 k primitives -2.5 .. -3.6 % with the striped
-// tile order; the 1 M-triangle scene of configs[4] +0.5 .. +7 % — mpt_ordered.h), the five-wave one beyond and for counted renders.
-#define MPT_OT6_MAX_PRIMS 600000u
+// sixth wave pays while a compute die's L2 can mostly hold the tree: 40 k / 99 k / 397 k / 596 k / 795 k primitives -4.4 / -4.0 / -2.7 /
+// -1.5 / -0.7 % with the striped tile order, 994 k +1.7 %, the 1 M-triangle height fields of configs[4] +1.5 .. +7 % — mpt_ordered.h,
+// gpurun_out/r05/s7, s9, s12), the five-wave one beyond and for counted renders.
+#define MPT_OT6_MAX_PRIMS 800000u
 static int ordered_point(const mpt_ctx* ctx, bool count) {
     if (count) return 0;
     if (ctx->ot_occ == 5) return 0;

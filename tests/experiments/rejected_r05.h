@@ -30,6 +30,19 @@
 //    against 16.63-16.69 ms (-1.7 %: the price of the 22 divisions), bunny x20 60.05 against 58.9 (+1.8 %: register allocation);
 //    guarded per lane (MPT_FAST_RCP=1): 16.56 (-0.5 %) / 59.06 (+0.2 %).  See DESIGN.md 5 for the wave-uniform guard's numbers.
 
+// 5. k_wavelocal, utilisation rules where it had none (the rule that pays in k_ordered: walk steps end when fewer than N lanes still walk):
+//    ring-0 steps (the bounce rays of 64 shaded hits; budget 8 trips, no rule): (8; 24, 24) scene.xml on the device-built tree 16.19 against
+//    16.41-16.48 ms (-1.6 %), but on the reference's tree 19.19 against 18.89-18.96 (+1.4 %) and Cornell 34.31 against 32.91-32.97 (+4 %);
+//    (1000; 32, 24): 16.19 / 19.47 / 34.35 — not a default (gpurun_out/r05/s13_ab_wl*.log).  PRIMARY steps (no budget, traced to the end;
+//    MPT_PRIMARY_MIN_ACTIVE = 12 / 16 / 24 / 32: stragglers parked in ring 1): 16.59-16.73 against 16.34-16.47, 19.4-19.5 against 18.8-19.0,
+//    33.1 against 32.9 — worse everywhere (s14_ab_pma*.log); the code is gone again.
+//
+// 6. k_wavelocal: another early-leave threshold of the box loop for the steps of the walk ring (the loop leaves for the leaf phase when fewer
+//    than 1/N of the lanes that entered still search; N = 8 everywhere): N = 2 / 3 / 4 / 16 for ring 1 only: scene.xml 16.71 / 16.51 / 16.30 /
+//    16.47 against 16.35-16.39 ms, reference tree 19.83 / 19.24 / 18.99 / 19.07 against 18.93-19.00, Cornell 32.86 / 33.15 / 33.07 / 32.98 against
+//    32.72-32.86 (s16_ab_le*.log): nothing.  k_ordered: its threshold 1/3 instead of 1/2: 54.95 against 54.0 ms [115.5 against 114.0-114.5];
+//    three walk rings 55.3 [118.7]; ONE walk ring 54.75 [113.05 against 114.0-114.5: mixed] (s15_ab*.log).
+//
 #if 0   // ---- 1. the carry loop (k_wavelocal) ---------------------------------------------------------------------------------------
 #if MPT_WL_CARRY
         // The end of a pass (round 5): the wave is out of path ids, this step parked nothing and its rings are empty — what is left is
