@@ -362,3 +362,39 @@ def test_walking_in_place_or_parking_gives_the_same_image(name, bsdf, inplace, m
         assert st["tree_parked"] > 0
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("occ", ["5", "6"])
+@pytest.mark.parametrize("order", ["0", "1", "3"])
+@pytest.mark.parametrize("name,W,H,bsdf,shards", [("bunny20.xml", 208, 117, 0, 1), ("glass.xml", 101, 67, 1, 3), ("scene.xml", 64, 40, 0, 5)])
+def test_both_operating_points_and_every_tile_order_give_the_oracle_image(name, W, H, bsdf, shards, order, occ, monkeypatch):
+    """Round 5: the closest-first kernel has two operating points (MPT_OT_OCC = 5: five workgroups of 256 threads per CU; 6: two of 768
+    with a step's bookkeeping spilled around the walk loops) and the pass a tile order in which every claim range = XCD gets a vertical
+    stripe of the image (MPT_TILE_ORDER = 3; 0 row-major with path -> pixel by arithmetic, 1 strided through the table).  Which waves
+    trace which paths in which order never enters the arithmetic: every combination renders the oracle's image, every float — ragged
+    sizes, tile shards whose tile counts do not divide by the eight claim ranges, fewer tiles than ranges (64 x 40 over 5 shards = 8
+    tiles each) included — and the shards add up to it."""
+    from metalpathtracer_amd import capi
+    monkeypatch.setenv("MPT_OT_OCC", occ)
+    monkeypatch.setenv("MPT_TILE_ORDER", order)
+    ctx = capi.Context(0)
+    try:
+        spp, depth = 3, 10
+        buf, uo = setup(ctx, name, W, H)
+        ref, ct = ob.render(uo, buf, rng_mode=ob.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, accumulate=1, sample_count=spp, seed=(9, 2), threads=8)
+        total = np.zeros_like(ref)
+        rays = 0
+        for r in range(shards):
+            ctx.clear_sum()
+            ctx.reset_stats()
+            ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, seed=(9, 2), pipeline=capi.PIPE_ORDERED,
+                       shard_rank=r, shard_count=shards)
+            total += ctx.read_sum()
+            rays += ctx.stats()["rays"]
+        _same(total, ref)
+        assert rays == ct["rays"]
+        ctx.clear_sum()                                    # the reference-order kernel walks the same tile tables
+        ctx.render(rng_mode=capi.RNG_PHILOX, bsdf_mode=bsdf, max_depth=depth, sample_count=spp, seed=(9, 2), pipeline=capi.PIPE_WAVELOCAL)
+        _same(ctx.read_sum(), ref)
+    finally:
+        ctx.close()

@@ -3,7 +3,7 @@
 # Counter passes (one rocprofv3 --pmc run per counter set, no tracing), the kernel summary of bench.py, the diagnostics-build
 # tables, the in-kernel clocks, the device-build and shard measurements.  Everything lands in gpurun_out/<tag>_*; run
 # `python tools/profiles_collect.py <tag>` afterwards (here) to turn it into profiles/<tag>_*.
-TAG=${1:-r04}; PART=${2:-all}    # part 1: counter passes + the bench lines; part 2: diagnostics tables, clocks, builds, configs (two GPU calls of <= 20 min)
+TAG=${1:-r05}; PART=${2:-all}    # part 1: counter passes + the bench lines; part 2: diagnostics tables, clocks, builds, configs (two GPU calls of <= 20 min)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}; OUT=$ROOT/gpurun_out; mkdir -p $OUT; LIB=$ROOT/metalpathtracer_amd/lib
 if [ "$PART" != 2 ]; then
 # one counter profile per workload of the bench line (the headline step and its four extras) + the two cross runs of round 3
@@ -33,6 +33,9 @@ find $OUT/devb_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT
 python3 tools/trace_timeline.py $(find $OUT/devb_trace -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_devbuild_timeline.txt 2>&1 || exit 1
 COUNT=1 SPP=128 JSON_OUT=$OUT/${TAG}_step_table.json MPT_LIB=$LIB/libmpt_hip_wavetimes.so timeout -k 10 300 python3 tools/gpu_wave_times.py > $OUT/${TAG}_step_table.txt 2>&1 || exit 1
 BVH=3 JSON_OUT=$OUT/${TAG}_ot_times_bunny20.json MPT_LIB=$LIB/libmpt_hip_times.so timeout -k 10 300 python3 tools/gpu_ot_times.py bunny20.xml 64 > $OUT/${TAG}_ot_times_bunny20.txt 2>&1 || exit 1
+BVH=3 MPT_LIB=$LIB/libmpt_hip_times.so timeout -k 10 300 python3 tools/gpu_ot_times.py config4 64 > $OUT/${TAG}_ot_times_config4.txt 2>&1 || exit 1
+{ echo "Where k_ordered's node and primitive bytes come from, and what its stack pops cost (diagnostics build -DMPT_OT_TIMES, tools/gpu_ot_times.py, 64 spp; VERDICT r4 item 1a):"; for w in bunny20 config4; do head -1 $OUT/${TAG}_ot_times_$w.txt; grep -h "served from LDS\|stack pops\|lane utilisation" $OUT/${TAG}_ot_times_$w.txt; done; } > $OUT/${TAG}_ot_lds_share.txt
+timeout -k 10 300 python3 tools/gpu_draw_fps.py > $OUT/${TAG}_draw_fps.txt 2>&1 || exit 1
 MPT_LIB=$LIB/libmpt_hip_clock.so timeout -k 10 300 python3 tools/gpu_clock.py > $OUT/${TAG}_inkernel_clock.txt 2>&1 || exit 1
 timeout -k 10 600 python3 tools/gpu_devbuild.py 64 > $OUT/${TAG}_devbuild.txt 2>&1 || exit 1
 timeout -k 10 600 python3 tools/gpu_shard_time.py > $OUT/${TAG}_shard_time.txt 2>&1 || exit 1
