@@ -257,6 +257,14 @@ int mpt_gpu_leaf_max(uint64_t n_prims);
  * closest-first walk fetches in their float form because their boxes could not be quantised (degenerate input; normally 0).  */
 int mpt_build_info(mpt_ctx* ctx, uint64_t out[8]);
 
+/* Diagnostics: a position-sensitive 64-bit digest of every device array of the uploaded scene, computed on the device —
+ * out[0..8] = threaded tree, primitive records, materials, own 4-wide tree, reference leaf boxes, per-primitive leaf boxes,
+ * always list, reference-format tree, reference-format primitive indices (0 where the scene has none); out[9..15] = the
+ * counts (nodes, primitives, materials, own nodes, reference leaves, always-list entries, own-tree depth).  Two builds of the
+ * same input must give the same 16 words (the tests' "same arrays" check covers what mpt_download_bvh does not return).
+ * No reference counterpart (the reference builds once, on the host: R/Scene/Scene.h:71-93).                                */
+int mpt_scene_digest(mpt_ctx* ctx, uint64_t out[16]);
+
 /* ---- multi-GPU: tile shards + ONE RCCL reduce of the HDR sum over xGMI ---------------------------------
  * The reference is single-GPU (it presents straight to the drawable, R/Renderer/Renderer.cpp:303-307); this is the
  * product's extension.  Every GPU renders the 8x8 pixel tiles t % N == rank (mpt_render_params.shard_rank / shard_count)

@@ -27,7 +27,7 @@ SYMBOLS = (
     "mpt_resize", "mpt_draw", "mpt_render", "mpt_render_async", "mpt_wait", "mpt_async_info", "mpt_sum_buffer", "mpt_set_sum_buffer", "mpt_clear_sum",
     "mpt_read_frame", "mpt_read_sum", "mpt_write_sum", "mpt_get_stats", "mpt_reset_stats", "mpt_stream", "mpt_synchronize",
     "mpt_trace_rays", "mpt_trace_rays_ordered", "mpt_accel_info", "mpt_kat_pcg", "mpt_kat_philox", "mpt_kat_sincos", "mpt_kat_rcp",
-    "mpt_build_bvh", "mpt_build_and_upload", "mpt_download_bvh", "mpt_gpu_leaf_max", "mpt_build_info", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
+    "mpt_build_bvh", "mpt_build_and_upload", "mpt_download_bvh", "mpt_gpu_leaf_max", "mpt_build_info", "mpt_scene_digest", "mpt_comm_unique_id", "mpt_comm_create_all", "mpt_comm_create_rank", "mpt_reduce_sum", "mpt_comm_destroy",
     "mpt_comm_last_error",
 )
 
@@ -151,6 +151,7 @@ def load():
     L.mpt_download_bvh.argtypes = [vp, fp, C.c_uint64, C.POINTER(C.c_uint64), ip]
     L.mpt_gpu_leaf_max.argtypes = [C.c_uint64]
     L.mpt_build_info.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.mpt_scene_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.mpt_comm_unique_id.argtypes = [vp]
     L.mpt_comm_create_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
     L.mpt_comm_create_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
@@ -409,6 +410,12 @@ class Context:
         nn = C.c_uint64()
         self._chk(self.L.mpt_download_bvh(self.h, _fp(bvh), nodes, C.byref(nn), _ip(idx)), "mpt_download_bvh")
         return bvh[: nn.value].copy(), idx[:n]
+
+    def scene_digest(self):
+        """16 words: digests of the scene's nine device arrays, then seven counts (include/mpt.h)"""
+        out = (C.c_uint64 * 16)()
+        self._chk(self.L.mpt_scene_digest(self.h, out), "mpt_scene_digest")
+        return [int(v) for v in out]
 
     def accel_info(self):
         out = (C.c_uint64 * 8)()

@@ -19,6 +19,7 @@
 #include "mpt_accel.h"
 #include "mpt_device.h"
 #include "mpt_lbvh.h"
+#include "mpt_radix.h"
 
 namespace mpt_devbuild {
 using mpt_lbvh::Radix;
@@ -34,13 +35,15 @@ struct Scalars {             // device-side results the host reads back once, at
     uint32_t n_mats;
     uint32_t n_leaves;
     uint32_t n_acc_nodes, acc_depth;
+    uint32_t mat_collision;  // two different materials with the same 32-bit sort key were seen (build() then sorts on all 64 bits)
 };
 
 __device__ __forceinline__ int span_of(const int2* range, int n, int node) { return node >= n - 1 ? 1 : range[node].y - range[node].x + 1; }
 __device__ __forceinline__ int first_of(const int2* range, int n, int node) { return node >= n - 1 ? node - (n - 1) : range[node].x; }
 
 // ---- materials: sort by a 64-bit hash, mark the runs, number them ---------------------------------------------------------
-__global__ void k_mat_hash(const float4* mats, uint32_t n, unsigned long long* keys, uint32_t* ids) {
+// keys: all 64 bits of the hash; keys32 (if not null): its upper half (& key_mask: the tests force collisions with a narrow one)
+__global__ void k_mat_hash(const float4* mats, uint32_t n, unsigned long long* keys, uint32_t* keys32, uint32_t key_mask, uint32_t* ids) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4 a = ((const uint4*)mats)[2 * (size_t)i], b = ((const uint4*)mats)[2 * (size_t)i + 1];
@@ -51,10 +54,12 @@ __global__ void k_mat_hash(const float4* mats, uint32_t n, unsigned long long* k
         h *= 0x100000001b3ull;
         h ^= h >> 29;
     }
-    keys[i] = h;
+    if (keys32) keys32[i] = (uint32_t)(h >> 32) & key_mask;
+    else keys[i] = h;
     ids[i] = i;
 }
-__global__ void k_mat_heads(const float4* mats, const uint32_t* ids, uint32_t n, uint32_t* head) {
+// keys32_sorted (if not null): a run of equal 32-bit keys that holds two different materials may hold them interleaved — flagged
+__global__ void k_mat_heads(const float4* mats, const uint32_t* ids, const uint32_t* keys32_sorted, uint32_t n, uint32_t* head, Scalars* sc) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     bool h = j == 0;
@@ -62,6 +67,7 @@ __global__ void k_mat_heads(const float4* mats, const uint32_t* ids, uint32_t n,
         const uint4* m = (const uint4*)mats;
         const uint4 a0 = m[2 * (size_t)ids[j]], a1 = m[2 * (size_t)ids[j] + 1], b0 = m[2 * (size_t)ids[j - 1]], b1 = m[2 * (size_t)ids[j - 1] + 1];
         h = a0.x != b0.x || a0.y != b0.y || a0.z != b0.z || a0.w != b0.w || a1.x != b1.x || a1.y != b1.y || a1.z != b1.z || a1.w != b1.w;
+        if (h && keys32_sorted && keys32_sorted[j] == keys32_sorted[j - 1]) sc->mat_collision = 1u;
     }
     head[j] = h ? 1u : 0u;
 }
@@ -92,7 +98,8 @@ __global__ void k_tri_extent(const float4* prims, uint32_t n, Scalars* sc) {
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63u) == 0 && m > 0.0f) atomicMax(&sc->tri_extent, __float_as_uint(m));
+    // (one atomic per wave that can still raise the value: 4096 same-address atomics were ~45 of the kernel's 57 us)
+    if ((threadIdx.x & 63u) == 0 && __float_as_uint(m) > __hip_atomic_load(&sc->tri_extent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&sc->tri_extent, __float_as_uint(m));
 }
 
 // ---- leaves: number them, lay their primitives out, their reference boxes, their own (sphere-free) boxes ----------------------
@@ -314,15 +321,10 @@ struct CollapseAcc {
     __device__ __forceinline__ float4 lo(int id) const { return id < TOP ? olo_b[id] : s_lo[id - TOP]; }
     __device__ __forceinline__ float4 hi(int id) const { return id < TOP ? ohi_b[id] : s_hi[id - TOP]; }
 };
-__global__ void k_collapse_root(const SahState* st, uint32_t* wbin) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) wbin[0] = (uint32_t)st->root;
-}
-__global__ void k_collapse_pick(CollapseAcc A, const uint32_t* wbin, uint32_t begin, uint32_t end, int4* picked, uint32_t* nint_out) {
-    const uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= end) return;
+// the <= 4 children of the wide node that stands on binary node b (-1: none), and how many of them are inner nodes
+__device__ __forceinline__ int4 collapse_pick(const CollapseAcc& A, int b, uint32_t* nint_out) {
     int ch[4] = {-1, -1, -1, -1};
     int nc = 0;
-    const int b = (int)wbin[k];
     if (b >= 0) {
         if (A.is_leaf(b)) {  // (only the root can be a leaf: a tree of one leaf)
             ch[nc++] = b;
@@ -347,17 +349,42 @@ __global__ void k_collapse_pick(CollapseAcc A, const uint32_t* wbin, uint32_t be
     }
     uint32_t nint = 0;
     for (int i = 0; i < nc; ++i) nint += A.is_leaf(ch[i]) ? 0u : 1u;
-    picked[k - begin] = make_int4(ch[0], ch[1], ch[2], ch[3]);
-    nint_out[k - begin] = nint;
+    *nint_out = nint;
+    return make_int4(ch[0], ch[1], ch[2], ch[3]);
 }
-__global__ void k_collapse_emit(CollapseAcc A, int n, const int2* range, const uint32_t* pfirst, uint32_t* wbin, uint32_t begin, uint32_t end, const int4* picked,
-                                const uint32_t* offs, float4* acc_nodes, uint32_t cap, const Scalars* sc) {
-    const uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= end || k >= cap) return;
+// No host wait inside the level loop (round 5; until round 4 the host read the size of the next level back after every level: 12 idle gaps
+// of ~20 us for 1 M primitives, and three more launches a level).  The levels' bounds live on the device (lev[L] = first node, end), the
+// grids are sized from an upper bound (a level has at most four times the nodes of the one before), and a node's children are PICKED by the
+// thread that emits their parent, so a level is one scan and one kernel.  The size of the next level goes to a slot of pinned host memory
+// with a stamp; the host reads it a level late, to end the loop (mpt_sah.h run_sah does the same).
+struct CollapseLevel {
+    uint32_t begin, end;
+};
+__global__ void k_collapse_root(CollapseAcc A, const SahState* st, int4* picked, uint32_t* nint, CollapseLevel* lev) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    picked[0] = collapse_pick(A, st->root, nint);
+    lev[0] = CollapseLevel{0u, 1u};
+}
+__global__ void k_collapse_level(CollapseAcc A, int n, const int2* range, const uint32_t* pfirst, CollapseLevel* lev, uint32_t L, const int4* picked, const uint32_t* offs,
+                                 int4* picked_next, uint32_t* nint_next, float4* acc_nodes, uint32_t cap, Scalars* sc, unsigned long long* host_slot, uint32_t stamp) {
+    const uint32_t begin = lev[L].begin, end = lev[L].end, cnt = end - begin;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        const uint32_t total = cnt ? offs[cnt] : 0u;   // inner children of the level = the nodes of the next one
+        lev[L + 1u] = CollapseLevel{end, end + total};
+        if (cnt) {
+            sc->n_acc_nodes = end;
+            sc->acc_depth = L + 1u;
+        }
+        // (ONE 8-byte store: no system-scope fence — a write-back of the L2 — beside the level's other workgroups; mpt_sah.h sah_level_prologue)
+        __hip_atomic_store(host_slot, (unsigned long long)stamp << 32 | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const uint32_t k = begin + t;
+    if (t >= cnt || k >= cap) return;
     const float pad = fmaxf(__uint_as_float(sc->tri_extent), 1e-6f) * 6.103515625e-05f;  // 2^-14: covers the rcp / fma slab arithmetic
-    const int4 p = picked[k - begin];
+    const int4 p = picked[t];
     const int ch[4] = {p.x, p.y, p.z, p.w};
-    const uint32_t at = end + offs[k - begin];
+    const uint32_t first = offs[t], at = end + first;
     float o[4 * MPT_OT_NODE_STRIDE];
     for (uint32_t q = 0; q < 4u * MPT_OT_NODE_STRIDE; ++q) o[q] = 0.0f;
     uint32_t j = 0;
@@ -372,7 +399,7 @@ __global__ void k_collapse_emit(CollapseAcc A, int n, const int2* range, const u
                 ref = MPT_ACCEL_LEAF | ((uint32_t)(span_of(range, n, ch[c]) - 1) << 27) | pfirst[ch[c]];
             } else {
                 ref = at + j;
-                if (at + j < cap) wbin[at + j] = (uint32_t)ch[c];
+                if (at + j < cap) picked_next[first + j] = collapse_pick(A, ch[c], nint_next + first + j);
                 ++j;
             }
         }
@@ -427,28 +454,66 @@ __global__ void k_always(Scalars* sc, float4* dprims, const float4* refleaf, flo
 // (d_prims_in: 3 float4 per primitive, d_mats_in: 2 float4 per primitive).  All outputs are hipMalloc'ed here and handed to
 // the caller (who frees them); scratch is freed on return.
 struct Built {
+    // views into `block` (ONE allocation, sized from upper bounds before the first kernel: n_out <= 2n - 1 nodes, <= n leaves, <= n + 2 wide
+    // nodes, <= n materials — ~390 bytes per primitive; until round 4 nine hipMallocs of the exact sizes sat on the build's critical path)
     float4 *nodes = nullptr, *prims = nullptr, *mats = nullptr, *acc_nodes = nullptr, *refleaf = nullptr, *refbox = nullptr, *always = nullptr;
     float4* ref_bvh = nullptr;   // the same tree in the reference's buffer format (2 float4 per node) ...
     int* ref_idx = nullptr;      // ... and its primitiveIndices
+    void* block = nullptr;
+    size_t block_bytes = 0;
     uint32_t n_nodes = 0, n_prims = 0, n_mats = 0, n_acc_nodes = 0, n_always = 0, n_ref_leaves = 0, acc_depth = 0, n_spheres = 0;
     float tri_extent = 0.0f;
     void release() {
-        hipFree(nodes); hipFree(prims); hipFree(mats); hipFree(acc_nodes); hipFree(refleaf); hipFree(refbox); hipFree(always); hipFree(ref_bvh); hipFree(ref_idx);
+        hipFree(block);
         *this = Built{};
     }
 };
+static size_t out_block_bytes(uint32_t n) {
+    const size_t nn = 2 * (size_t)n - 1, al = 256;
+    const size_t parts[9] = {nn * 32, (size_t)n * 4, (size_t)n * 48, (size_t)n * 32, nn * 32, ((size_t)n + 2) * MPT_OT_NODE_STRIDE * 16, (size_t)MPT_ACCEL_MAX_ALWAYS * 80,
+                             (size_t)n * 32, (size_t)n * 32};
+    size_t total = 0;
+    for (size_t b : parts) total += (b + al - 1) & ~(al - 1);
+    return total;
+}
 
-static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint, Built& out,
-                        mpt_lbvh::ScratchPool* pool = nullptr) {
+// spare / spare_bytes (in, out): a device allocation the caller has no more use for — taken for the outputs if it is large enough.
+static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint, Built& out,
+                             mpt_lbvh::ScratchPool* pool, void** spare, size_t* spare_bytes, bool wide_mat_sort, bool* mat_collision) {
     Scratch sc(pool);
+    {
+        const size_t need = out_block_bytes(n);
+        if (spare && *spare && *spare_bytes >= need) {
+            out.block = *spare;
+            out.block_bytes = *spare_bytes;
+            *spare = nullptr;
+            *spare_bytes = 0;
+        } else {
+            MPT_LB(hipMalloc(&out.block, need));
+            out.block_bytes = need;
+        }
+        char* q = (char*)out.block;
+        auto carve = [&](size_t bytes) {
+            char* r = q;
+            q += (bytes + 255) & ~(size_t)255;
+            return r;
+        };
+        const size_t nn_ = 2 * (size_t)n - 1;
+        out.ref_bvh = (float4*)carve(nn_ * 32);
+        out.ref_idx = (int*)carve((size_t)n * 4);
+        out.prims = (float4*)carve((size_t)n * 48);
+        out.refleaf = (float4*)carve((size_t)n * 32);
+        out.nodes = (float4*)carve(nn_ * 32);
+        out.acc_nodes = (float4*)carve(((size_t)n + 2) * MPT_OT_NODE_STRIDE * 16);
+        out.always = (float4*)carve((size_t)MPT_ACCEL_MAX_ALWAYS * 80);
+        out.refbox = (float4*)carve((size_t)n * 32);
+        out.mats = (float4*)carve((size_t)n * 32);
+    }
     MPT_LB(sc.reserve((size_t)n * 720 + ((size_t)8 << 20)));   // (measured: ~620 bytes per primitive)
     Radix R;
     Scalars* d_sc;
-    struct Pinned {   // read-backs of a few words per level go through pinned memory (a pageable target costs ~0.3 ms per copy)
-        uint32_t* p = nullptr;
-        ~Pinned() { if (p) hipHostFree(p); }
-    } pinned;
-    MPT_LB(hipHostMalloc((void**)&pinned.p, 1024, hipHostMallocDefault));   // (words 64.. : the level slots of mpt_sah::run_sah)
+    mpt_lbvh::PinnedWords pinned;   // read-backs of a few words go through pinned memory (a pageable target costs ~0.3 ms per copy)
+    MPT_LB(pinned.get(pool, 0));    // (words 64 .. 95: the level slots of mpt_sah::run_sah, 128 .. 143: the collapse's, 192 ..: the scalars read at the end)
     uint32_t* pin = pinned.p;
     MPT_LB(sc.alloc(&d_sc, 1));
     MPT_LB(hipMemsetAsync(d_sc, 0, sizeof(Scalars), stream));
@@ -457,36 +522,58 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     // materials
     unsigned long long *mk, *mk2;
     uint32_t *mi, *mi2, *mhead, *mrank, *mat_of_prim;
-    float4* mtable;
-    MPT_LB(sc.alloc(&mk, n));
-    MPT_LB(sc.alloc(&mk2, n));
+    float4* const mtable = out.mats;   // (the de-duplicated table is written where it stays)
+    mk = mk2 = nullptr;
+    if (wide_mat_sort) {
+        MPT_LB(sc.alloc(&mk, n));
+        MPT_LB(sc.alloc(&mk2, n));
+    }
     MPT_LB(sc.alloc(&mi, n));
     MPT_LB(sc.alloc(&mi2, n));
     MPT_LB(sc.alloc(&mhead, n));
     MPT_LB(sc.alloc(&mrank, n));
     MPT_LB(sc.alloc(&mat_of_prim, n));
-    MPT_LB(sc.alloc(&mtable, 2 * (size_t)n));
-    hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, stream, d_mats_in, n, mk, mi);
+    // Sorted on the upper 32 bits of the hash, as 32-bit keys, by four passes of the builders' own radix sort (mpt_radix.h: hipcub sorts
+    // 1 M pairs by merging, 25 launches and ~0.2 ms whatever the key width).  The order is that of the full 64-bit sort unless two DIFFERENT materials share those 32 bits —
+    // k_mat_heads sees that (equal keys, other contents) and the caller builds again with wide_mat_sort (build() below).
+    // [hipcub::DeviceRadixSort::SortPairs over bits [32, 64) of the 64-bit keys themselves — the obvious way to do this — is WRONG on this
+    // toolchain (ROCm 7.2.0, gfx950) from a few thousand items on: the keys it returns are not even a permutation of its input
+    // (tests/experiments/hipcub_partial_bits.hip, run on MI355X: 4,971 / 99,362 / 1,000,003 items, its own queried temporary size, canaries
+    // behind every buffer intact, input untouched; 5 items: right).  That is what round 4's experiment hit: material ids from garbage keys
+    // — images off in 1.5 % of the pixels, and once ids far outside the table, a memory fault inside this build (gpurun_out/r04/
+    // s46_tests.log).  The same program finds every range the product uses right: [0, 64), [0, 63) (mpt_lbvh.h), [0, 13), [0, 8) on
+    // 32-bit keys (docs/HISTORY.md); full-width 32-bit keys are checked by the recorded digests, tests/golden/devbuild_digests.json.]
+    uint32_t *mk32 = nullptr, *mk32s = nullptr;
+    if (!wide_mat_sort) {
+        MPT_LB(sc.alloc(&mk32, n));
+        MPT_LB(sc.alloc(&mk32s, n));
+    }
+    uint32_t key_mask = 0xFFFFFFFFu;
+    if (const char* e = getenv("MPT_DEBUG_MAT_KEY_MASK")) key_mask = (uint32_t)strtoul(e, nullptr, 16);
+    hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, stream, d_mats_in, n, mk, mk32, key_mask, mi);
     {
-        // All 64 bits.  hipcub::DeviceRadixSort::SortPairs over bits [32, 64) of 64-bit keys — four radix passes instead of eight — is
-        // WRONG on this toolchain (ROCm 7.2.0, gfx950) from a few thousand items on: the keys it returns are not even a permutation of
-        // its input (tests/experiments/hipcub_partial_bits.hip, run on MI355X: 4,971 / 99,362 / 1,000,003 items, material hashes and random
-        // keys, its own queried temporary size, canaries behind every buffer intact, input untouched; 5 items: right).  That is what round
-        // 4's experiment hit: material ids from garbage keys — images off in 1.5 % of the pixels, and once ids far outside the table, a
-        // memory fault inside this build and the abort of gpurun_out/r04/s46_tests.log.  The same program finds every range the product
-        // DOES use right at all four sizes: [0, 64) here, [0, 63) (mpt_lbvh.h), [0, 13) and [0, 8) on 32-bit keys below (docs/HISTORY.md).
-        size_t bytes = 0;
-        MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, stream));
-        char* tmp;
-        MPT_LB(sc.alloc(&tmp, bytes));
-        MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, stream));
-        hipLaunchKernelGGL(k_mat_heads, dim3(gn), dim3(B), 0, stream, d_mats_in, (const uint32_t*)mi2, n, mhead);
+        const uint32_t *ids_sorted = mi2, *keys32_sorted = nullptr;
+        if (wide_mat_sort) {
+            size_t bytes = 0;
+            MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, stream));
+            char* tmp;
+            MPT_LB(sc.alloc(&tmp, bytes));
+            MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, stream));
+        } else {
+            mpt_radix::RadixTemp RT;
+            MPT_LB(mpt_radix::radix_reserve(sc, n, stream, RT));
+            bool second = false;
+            MPT_LB(mpt_radix::radix_sort_pairs(stream, RT, mk32, mi, mk32s, mi2, n, 4, &second));
+            ids_sorted = second ? mi2 : mi;
+            keys32_sorted = second ? mk32s : mk32;
+        }
+        hipLaunchKernelGGL(k_mat_heads, dim3(gn), dim3(B), 0, stream, d_mats_in, ids_sorted, keys32_sorted, n, mhead, d_sc);
         size_t sb = 0;
         MPT_LB(hipcub::DeviceScan::InclusiveSum(nullptr, sb, mhead, mrank, (int)n, stream));
         char* tmp2;
         MPT_LB(sc.alloc(&tmp2, sb));
         MPT_LB(hipcub::DeviceScan::InclusiveSum(tmp2, sb, mhead, mrank, (int)n, stream));
-        hipLaunchKernelGGL(k_mat_scatter, dim3(gn), dim3(B), 0, stream, d_mats_in, (const uint32_t*)mi2, (const uint32_t*)mhead, (const uint32_t*)mrank, n,
+        hipLaunchKernelGGL(k_mat_scatter, dim3(gn), dim3(B), 0, stream, d_mats_in, ids_sorted, (const uint32_t*)mhead, (const uint32_t*)mrank, n,
                            mat_of_prim, mtable, d_sc);
     }
     // the binary tree
@@ -494,8 +581,6 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     const uint32_t n_out = R.n_out;
     const size_t nn = 2 * (size_t)n - 1;
     const uint32_t gnn = (uint32_t)((nn + B - 1) / B), go = (n_out + B - 1) / B;
-    MPT_LB(hipMalloc(&out.ref_bvh, (size_t)n_out * 32));
-    MPT_LB(hipMalloc(&out.ref_idx, (size_t)n * 4));
     MPT_LB(mpt_lbvh::emit_reference_format(stream, R, out.ref_bvh, out.ref_idx));
     // leaves
     uint32_t *is_leaf, *leaf_id;
@@ -513,8 +598,6 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
         MPT_LB(sc.alloc(&tmp, sb));
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp, sb, is_leaf, leaf_id, (int)nn + 1, stream));
     }
-    MPT_LB(hipMalloc(&out.prims, (size_t)n * 48));
-    MPT_LB(hipMalloc(&out.refleaf, (size_t)n_out * 32));   // (leaves <= output nodes)
     const int use_always = n_spheres_hint <= MPT_ACCEL_MAX_ALWAYS ? 1 : 0;
     // where each leaf's records go (see k_leaf_keys)
     uint32_t* pfirst;
@@ -559,15 +642,13 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     MPT_LB(sc.alloc(&skip, nn));
     hipLaunchKernelGGL(k_depth_skip, dim3(gnn), dim3(B), 0, stream, (int)n, (const uint32_t*)R.keep, (const uint32_t*)R.index, (const int2*)R.child,
                        (const int*)R.parent, depth_c, id_c, skip);
-    {
-        size_t bytes = 0;
-        MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, depth_c, depth_s, id_c, order, (int)n_out, 0, 8, stream));
-        char* tmp;
-        MPT_LB(sc.alloc(&tmp, bytes));
-        MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, depth_c, depth_s, id_c, order, (int)n_out, 0, 8, stream));
+    {   // (one counting pass over the 8-bit depths, stable: breadth-first, the builder's order within a level)
+        mpt_radix::RadixTemp RT;
+        MPT_LB(mpt_radix::radix_reserve(sc, n_out, stream, RT));
+        bool second = false;
+        MPT_LB(mpt_radix::radix_sort_pairs(stream, RT, depth_c, id_c, depth_s, order, n_out, 1, &second));
     }
     hipLaunchKernelGGL(k_positions, dim3(go), dim3(B), 0, stream, n_out, (const uint32_t*)order, tpos);
-    MPT_LB(hipMalloc(&out.nodes, (size_t)n_out * 32));
     hipLaunchKernelGGL(k_emit_threaded, dim3(go), dim3(B), 0, stream, n_out, (int)n, (const uint32_t*)order, (const uint32_t*)tpos, (const uint32_t*)is_leaf,
                        (const int2*)R.child, (const int2*)R.range, (const uint32_t*)pfirst, (const int*)skip, (const float4*)R.nlo, (const float4*)R.nhi, out.nodes);
     // own tree: its binary tree (the builder's own SAH tree refitted, or a binned SAH over the leaves: mpt_sah.h), then the 4-wide collapse
@@ -616,52 +697,70 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
         s_lo = T.lo;
         s_hi = T.hi;
     }
-    const uint32_t cap = max_items + 2u;   // wide nodes <= inner nodes of the SAH tree (+ the root of a one-leaf tree)
-    uint32_t *wbin, *c_nint, *c_offs;
-    int4* c_picked;
-    MPT_LB(sc.alloc(&wbin, cap));
-    MPT_LB(sc.alloc(&c_nint, cap + 1));
-    MPT_LB(sc.alloc(&c_offs, cap + 1));
-    MPT_LB(sc.alloc(&c_picked, cap));
-    MPT_LB(hipMalloc(&out.acc_nodes, (size_t)cap * MPT_OT_NODE_STRIDE * 16));
-    uint32_t acc_nodes_n = 0, acc_depth = 0;
+    const uint32_t cap = std::min(max_items, n) + 2u;   // wide nodes <= inner nodes of the SAH tree over the leaves (+ the root of a one-leaf tree)
     {
+        uint32_t *nint_a, *nint_b, *c_offs;
+        int4 *picked_a, *picked_b;
+        CollapseLevel* lev;
+        MPT_LB(sc.alloc(&nint_a, cap + 1));
+        MPT_LB(sc.alloc(&nint_b, cap + 1));
+        MPT_LB(sc.alloc(&c_offs, cap + 1));
+        MPT_LB(sc.alloc(&picked_a, cap));
+        MPT_LB(sc.alloc(&picked_b, cap));
+        MPT_LB(sc.alloc(&lev, 130));
         const CollapseAcc A = {s_child, s_lo, s_hi, olo, ohi, (int)(2 * n - 1)};
         size_t sb = 0;
-        MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, c_nint, c_offs, (int)cap + 1, stream));
+        MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, nint_a, c_offs, (int)cap + 1, stream));
         char* tmp;
         MPT_LB(sc.alloc(&tmp, sb));
-        hipLaunchKernelGGL(k_collapse_root, dim3(1), dim3(64), 0, stream, (const SahState*)d_st, wbin);
-        uint32_t begin = 0, end = 1;
-        while (begin < end && end <= cap) {
-            const uint32_t cnt = end - begin, g = (cnt + B - 1) / B;
-            ++acc_depth;
-            hipLaunchKernelGGL(k_collapse_pick, dim3(g), dim3(B), 0, stream, A, (const uint32_t*)wbin, begin, end, c_picked, c_nint);
-            MPT_LB(hipMemsetAsync(c_nint + cnt, 0, 4, stream));
-            MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp, sb, c_nint, c_offs, (int)cnt + 1, stream));
-            hipLaunchKernelGGL(k_collapse_emit, dim3(g), dim3(B), 0, stream, A, (int)n, (const int2*)R.range, (const uint32_t*)pfirst, wbin, begin, end, (const int4*)c_picked,
-                               (const uint32_t*)c_offs, out.acc_nodes, cap, (const Scalars*)d_sc);
-            MPT_LB(hipMemcpyAsync(pin, c_offs + cnt, 4, hipMemcpyDeviceToHost, stream));
-            MPT_LB(hipStreamSynchronize(stream));
-            begin = end;
-            end = end + pin[0];
+        static uint32_t s_epoch = 0;
+        const uint32_t epoch = (++s_epoch & 0xFFFFu) << 16;
+        volatile unsigned long long* slots = (volatile unsigned long long*)(pin + 128);   // eight slots of (stamp << 32 | size of the next level), behind run_sah's
+        unsigned long long* d_slots = nullptr;
+        MPT_LB(hipHostGetDevicePointer((void**)&d_slots, pin + 128, 0));
+        for (int q = 0; q < 8; ++q) slots[q] = 0ull;
+        hipLaunchKernelGGL(k_collapse_root, dim3(1), dim3(64), 0, stream, A, (const SahState*)d_st, picked_a, nint_a, lev);
+        uint32_t bound = 1;   // upper bound of the level about to be enqueued
+        bool done = false;
+        for (uint32_t L = 0; L < 128u && !done; ++L) {
+            MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp, sb, nint_a, c_offs, (int)bound + 1, stream));
+            hipLaunchKernelGGL(k_collapse_level, dim3((bound + B - 1) / B), dim3(B), 0, stream, A, (int)n, (const int2*)R.range, (const uint32_t*)pfirst, lev, L,
+                               (const int4*)picked_a, (const uint32_t*)c_offs, picked_b, nint_b, out.acc_nodes, cap, d_sc, d_slots + (L & 7u),
+                               epoch | (L + 1u));
+            MPT_LB(hipGetLastError());
+            uint32_t next_bound = (uint32_t)std::min<uint64_t>(4ull * bound, cap);
+            if (L >= 1u) {   // the size of level L (slot L - 1), which the device is at or past: nothing there = the tree is complete
+                volatile unsigned long long* sl = slots + ((L - 1u) & 7u);
+                const uint32_t want = epoch | L;
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned long long spin = 0; (uint32_t)(*sl >> 32) != want; ++spin)
+                    if ((spin & 0xFFFu) == 0xFFFu) {
+                        const hipError_t q = hipStreamQuery(stream);
+                        if (q != hipSuccess && q != hipErrorNotReady) return q;
+                        if (q == hipSuccess && (uint32_t)(*sl >> 32) != want) return hipErrorUnknown;   // the stream is drained and the stamp never came
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return hipErrorLaunchTimeOut;
+                    }
+                const uint32_t size_L = (uint32_t)*sl;
+                if (size_L == 0u) done = true;
+                next_bound = (uint32_t)std::min<uint64_t>(4ull * size_L, cap);
+            }
+            bound = std::max(next_bound, 1u);
+            std::swap(nint_a, nint_b);
+            std::swap(picked_a, picked_b);
         }
-        acc_nodes_n = begin;
+        if (!done) return hipErrorUnknown;
     }
-    MPT_LB(hipMalloc(&out.always, (size_t)MPT_ACCEL_MAX_ALWAYS * 80));
     hipLaunchKernelGGL(k_always, dim3(1), dim3(64), 0, stream, d_sc, out.prims, (const float4*)out.refleaf, out.always);
     MPT_LB(hipGetLastError());
-    MPT_LB(hipMalloc(&out.refbox, (size_t)n * 32));
     hipLaunchKernelGGL(k_prim_refbox, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const float4*)out.prims, (const float4*)out.refleaf, n, out.refbox);
     MPT_LB(hipGetLastError());
-    Scalars h;
+    Scalars& h = *(Scalars*)(pin + 192);   // (pinned: a pageable target costs ~0.3 ms per copy)
+    static_assert(sizeof(Scalars) + 4 <= 256, "Scalars must fit the last quarter of the pinned block");
+    uint32_t& n_leaves = pin[192 + sizeof(Scalars) / 4];
     MPT_LB(hipMemcpyAsync(&h, d_sc, sizeof h, hipMemcpyDeviceToHost, stream));
-    uint32_t n_leaves = 0;
     MPT_LB(hipMemcpyAsync(&n_leaves, leaf_id + nn, 4, hipMemcpyDeviceToHost, stream));
     MPT_LB(hipStreamSynchronize(stream));
-    MPT_LB(hipMalloc(&out.mats, (size_t)std::max(h.n_mats, 1u) * 32));
-    MPT_LB(hipMemcpyAsync(out.mats, mtable, (size_t)h.n_mats * 32, hipMemcpyDeviceToDevice, stream));
-    MPT_LB(hipStreamSynchronize(stream));
+    const uint32_t acc_nodes_n = h.n_acc_nodes, acc_depth = h.acc_depth;
     out.n_nodes = n_out;
     out.n_prims = n;
     out.n_mats = h.n_mats;
@@ -671,7 +770,22 @@ static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_
     out.n_always = h.n_spheres <= MPT_ACCEL_MAX_ALWAYS ? h.n_spheres : 0u;
     out.n_ref_leaves = n_leaves;
     memcpy(&out.tri_extent, &h.tri_extent, 4);
+    *mat_collision = h.mat_collision != 0u;
     return hipSuccess;
+}
+static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint, Built& out,
+                        mpt_lbvh::ScratchPool* pool = nullptr, void** spare = nullptr, size_t* spare_bytes = nullptr) {
+    bool collision = false;
+    MPT_LB(build_pass(stream, d_prims_in, d_mats_in, n, leaf_max, builder, n_spheres_hint, out, pool, spare, spare_bytes, false, &collision));
+    if (!collision) return hipSuccess;
+    // two different materials share the upper half of their hashes (one scene in ~2^33 / materials^2): once more, sorted on all 64 bits,
+    // into the same block
+    void* block = out.block;
+    size_t bytes = out.block_bytes;
+    out = Built{};
+    const hipError_t e = build_pass(stream, d_prims_in, d_mats_in, n, leaf_max, builder, n_spheres_hint, out, pool, &block, &bytes, true, &collision);
+    if (block) hipFree(block);   // (not taken: the pass failed before it got there)
+    return e;
 }
 
 }  // namespace mpt_devbuild

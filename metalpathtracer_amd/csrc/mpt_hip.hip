@@ -164,6 +164,12 @@ struct mpt_ctx {
     uint32_t built_leaf_max = 0;     // leaf limit of that tree (mpt_build_info)
     uint32_t ot_stack_depth = 8;     // LDS stack entries per lane (MPT_OT_STACK); deeper entries spill to global memory
     mpt_lbvh::ScratchPool build_pool;  // scratch chunks of the GPU builders, kept between builds (<= 2 GiB)
+    // The arrays of a scene made by mpt_build_and_upload are views into ONE device allocation (scene_block: nine hipMallocs on the
+    // build's critical path were ~0.3 ms of a 4.3 ms build); the block of the scene before is kept as the next build's (spare_block),
+    // so a rebuild allocates nothing and a failed build leaves the old scene intact.  Scenes of mpt_upload_scene own their arrays one by one.
+    void* scene_block = nullptr;
+    void* spare_block = nullptr;
+    size_t scene_block_bytes = 0, spare_block_bytes = 0;
     OtBudgets ot_budgets = default_ot_budgets();
     float tri_extent = 0.0f, acc_eps_abs = 0.0f, acc_cull_rel = 9.765625e-4f;
     bool acc_ok = false;             // the closest-first pipeline may be used for this scene
@@ -388,6 +394,33 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
     return MPT_OK;
 }
 
+// Lets go of the scene's device arrays: one by one (mpt_upload_scene's), or the block they are views into (mpt_build_and_upload's), which
+// becomes the spare block of the next build if that has none and it is not larger than 1 GiB.
+static void free_scene_buffers(mpt_ctx* ctx, bool keep_spare) {
+    if (ctx->scene_block) {
+        if (keep_spare && !ctx->spare_block && ctx->scene_block_bytes <= ((size_t)1 << 30)) {
+            ctx->spare_block = ctx->scene_block;
+            ctx->spare_block_bytes = ctx->scene_block_bytes;
+        } else {
+            hipFree(ctx->scene_block);
+        }
+        ctx->scene_block = nullptr;
+        ctx->scene_block_bytes = 0;
+    } else {
+        hipFree(ctx->d_nodes);
+        hipFree(ctx->d_prims);
+        hipFree(ctx->d_mats);
+        hipFree(ctx->d_acc_nodes);
+        hipFree(ctx->d_refbox);
+        hipFree(ctx->d_refleaf);
+        hipFree(ctx->d_always);
+        hipFree(ctx->d_ref_bvh);
+        hipFree(ctx->d_ref_idx);
+    }
+    ctx->d_nodes = ctx->d_prims = ctx->d_mats = ctx->d_acc_nodes = ctx->d_refbox = ctx->d_refleaf = ctx->d_always = ctx->d_ref_bvh = nullptr;
+    ctx->d_ref_idx = nullptr;
+}
+
 static void free_ot_rings(OtRings& r) {
     hipFree(r.base);
     r = OtRings{};
@@ -409,15 +442,8 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
     hipSetDevice(ctx->device);
     for (Lane& L : ctx->lane)
         if (L.stream) hipStreamSynchronize(L.stream);
-    hipFree(ctx->d_nodes);
-    hipFree(ctx->d_prims);
-    hipFree(ctx->d_mats);
-    hipFree(ctx->d_acc_nodes);
-    hipFree(ctx->d_refbox);
-    hipFree(ctx->d_refleaf);
-    hipFree(ctx->d_always);
-    hipFree(ctx->d_ref_bvh);
-    hipFree(ctx->d_ref_idx);
+    free_scene_buffers(ctx, false);
+    hipFree(ctx->spare_block);
     hipFree(ctx->d_accum[0]);
     hipFree(ctx->d_accum[1]);
     hipFree(ctx->d_sum_own);
@@ -815,16 +841,7 @@ static int upload_scene_impl(mpt_ctx* ctx, const float* bvh, uint64_t n_nodes, c
         }
     }
 
-    hipFree(ctx->d_nodes);
-    hipFree(ctx->d_prims);
-    hipFree(ctx->d_mats);
-    hipFree(ctx->d_acc_nodes);
-    hipFree(ctx->d_refleaf);
-    hipFree(ctx->d_always);
-    hipFree(ctx->d_ref_bvh);
-    hipFree(ctx->d_ref_idx);
-    ctx->d_nodes = ctx->d_prims = ctx->d_mats = ctx->d_acc_nodes = ctx->d_refleaf = ctx->d_always = ctx->d_ref_bvh = nullptr;
-    ctx->d_ref_idx = nullptr;
+    free_scene_buffers(ctx, true);
     ctx->n_ref_nodes = 0;
     ctx->built_leaf_max = 0;
     ctx->have_scene = false;
@@ -1813,7 +1830,8 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     }
     hipEventRecord(e0, ctx->stream);
     mpt_devbuild::Built b;
-    hipError_t e = mpt_devbuild::build(ctx->stream, (float4*)d_p.p, (const float4*)d_m.p, n, leaf_max, gpu_builder(), n_spheres, b, &ctx->build_pool);
+    hipError_t e = mpt_devbuild::build(ctx->stream, (float4*)d_p.p, (const float4*)d_m.p, n, leaf_max, gpu_builder(), n_spheres, b, &ctx->build_pool, &ctx->spare_block,
+                                       &ctx->spare_block_bytes);
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -1828,21 +1846,15 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
         b.release();
         return fail(ctx, MPT_ERR_HIP, "GPU BVH build: sphere count mismatch (internal)");
     }
-    hipFree(ctx->d_nodes);
-    hipFree(ctx->d_prims);
-    hipFree(ctx->d_mats);
-    hipFree(ctx->d_acc_nodes);
-    hipFree(ctx->d_refleaf);
-    hipFree(ctx->d_always);
-    hipFree(ctx->d_ref_bvh);
-    hipFree(ctx->d_ref_idx);
+    free_scene_buffers(ctx, true);   // (the old scene's block becomes the next build's)
+    ctx->scene_block = b.block;
+    ctx->scene_block_bytes = b.block_bytes;
     ctx->d_nodes = b.nodes;
     ctx->d_prims = b.prims;
     ctx->d_mats = b.mats;
     ctx->d_acc_nodes = b.acc_nodes;
     ctx->n_acc_nodes = b.n_acc_nodes;
     ctx->d_refleaf = b.refleaf;
-    hipFree(ctx->d_refbox);
     ctx->d_refbox = b.refbox;
     ctx->d_always = b.always;
     ctx->d_ref_bvh = b.ref_bvh;
@@ -2063,6 +2075,47 @@ extern "C" int mpt_accel_info(mpt_ctx* ctx, uint64_t out[8]) {
 }
 
 extern "C" int mpt_gpu_leaf_max(uint64_t n_prims) { return gpu_leaf_max(n_prims); }
+
+// Position-sensitive 64-bit digest of a device array of 32-bit words: sum over i of splitmix64(i << 32 | word[i]) (a commutative sum, so
+// the order in which the waves add is free).  What the tests compare two builds of a scene by, array by array (mpt_scene_digest).
+__global__ void k_digest(const uint32_t* w, uint64_t n_words, unsigned long long* out) {
+    unsigned long long acc = 0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (i << 32 | w[i]) + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        acc += z ^ (z >> 31);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(out, acc);
+}
+extern "C" int mpt_scene_digest(mpt_ctx* ctx, uint64_t out[16]) {
+    return guarded(ctx, [&]() -> int {
+        if (!ctx || !out) return MPT_ERR_INVALID_ARG;
+        if (!ctx->have_scene) return fail(ctx, MPT_ERR_NOT_READY, "no scene");
+        HIPCHK(hipSetDevice(ctx->device));
+        const bool built = ctx->d_ref_bvh != nullptr;
+        struct Arr { const void* p; uint64_t words; } a[9] = {
+            {ctx->d_nodes, (uint64_t)ctx->n_nodes * 8}, {ctx->d_prims, (uint64_t)ctx->n_prims * 12}, {ctx->d_mats, (uint64_t)ctx->n_mats * 8},
+            {ctx->d_acc_nodes, (uint64_t)ctx->n_acc_nodes * MPT_OT_NODE_STRIDE * 4}, {ctx->d_refleaf, (uint64_t)ctx->n_ref_leaves * 8},
+            {ctx->d_refbox, ctx->d_refbox ? (uint64_t)ctx->n_prims * 8 : 0u}, {ctx->d_always, (uint64_t)ctx->n_always * 20},
+            {ctx->d_ref_bvh, built ? (uint64_t)ctx->n_ref_nodes * 8 : 0u}, {ctx->d_ref_idx, built ? (uint64_t)ctx->n_prims : 0u}};
+        DevBuf d;
+        HIPCHK(d.alloc(16 * 8));
+        HIPCHK(hipMemsetAsync(d.p, 0, 16 * 8, ctx->stream));
+        for (int k = 0; k < 9; ++k)
+            if (a[k].p && a[k].words) {
+                const uint32_t g = (uint32_t)std::min<uint64_t>((a[k].words + 255) / 256, 2048);
+                hipLaunchKernelGGL(k_digest, dim3(g), dim3(256), 0, ctx->stream, (const uint32_t*)a[k].p, a[k].words, (unsigned long long*)d.p + k);
+            }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, d.p, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const uint64_t counts[7] = {ctx->n_nodes, ctx->n_prims, ctx->n_mats, ctx->n_acc_nodes, ctx->n_ref_leaves, ctx->n_always, ctx->acc_depth};
+        for (int k = 0; k < 7; ++k) out[9 + k] = counts[k];
+        return MPT_OK;
+    });
+}
 
 extern "C" int mpt_build_info(mpt_ctx* ctx, uint64_t out[8]) {
     if (!ctx || !out) return MPT_ERR_INVALID_ARG;

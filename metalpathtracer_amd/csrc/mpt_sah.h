@@ -21,10 +21,34 @@ namespace mpt_lbvh {
 struct ScratchPool {
     std::vector<std::pair<void*, size_t>> chunks;
     size_t keep_bytes = (size_t)2 << 30;   // what stays allocated between builds at most
+    uint32_t* pin = nullptr;               // 2 KiB of pinned host memory for the builders' read-backs (hipHostMalloc per build: ~0.1 ms each)
     ~ScratchPool() { release(); }
     void release() {
         for (auto& c : chunks) hipFree(c.first);
         chunks.clear();
+        if (pin) hipHostFree(pin);
+        pin = nullptr;
+    }
+};
+// 1 KiB of pinned host memory for one builder's read-backs: part `which` (0 / 1) of the pool's block, or the builder's own for the call
+struct PinnedWords {
+    uint32_t* p = nullptr;
+    bool own = false;
+    PinnedWords() = default;
+    PinnedWords(const PinnedWords&) = delete;
+    PinnedWords& operator=(const PinnedWords&) = delete;
+    ~PinnedWords() { if (own && p) hipHostFree(p); }
+    hipError_t get(ScratchPool* pool, int which) {
+        if (pool) {
+            if (!pool->pin) {
+                const hipError_t e = hipHostMalloc((void**)&pool->pin, 2048, hipHostMallocDefault);
+                if (e != hipSuccess) return e;
+            }
+            p = pool->pin + 256 * which;
+            return hipSuccess;
+        }
+        own = true;
+        return hipHostMalloc((void**)&p, 1024, hipHostMallocDefault);
     }
 };
 struct Scratch {
@@ -118,13 +142,16 @@ struct SahTask {
 #define MPT_SAH_SMALL 8u     // tasks of at most this many items (8 or 16) are FINISHED, sub-tree and all, by as many lanes (k_sah_small)
 #endif
 struct SahState {
-    uint32_t n_next;        // tasks pushed for the next level (a wave each)
-    uint32_t n_next_big;    // ... the big ones (a workgroup each)
-    uint32_t n_next_small;  // ... and the small ones (a lane per item)
-    uint32_t n_nodes;  // inner nodes created
-    int root;          // -1: no items
+    // Task counts by level, three sets in rotation: the kernels of level L read cnt[L % 3] (what level L - 1 pushed), push into
+    // cnt[(L + 1) % 3], and the level's first kernel zeroes cnt[(L + 2) % 3] for the level after (sah_level_prologue) — nobody else
+    // touches that set during level L, so no kernel of its own is needed between two levels (round 4 had one: k_sah_flip, 23 launches).
+    // (a set per 64-byte line: every wave of a level READS its set, and the line the pushes' atomics hammer must not be the same one — in
+    //  one line the levels of 30 k .. 130 k tasks took twice as long, 114 / 193 / 82 -> 202 / 397 / 155 us)
+    uint32_t cnt[3][48];  // [set][16 * kind]: kind 0 = mid tasks (a wave each), 1 = big tasks (a workgroup per chunk), 2 = small tasks (a lane per item);
+                          // a line per counter as well: the three push counters of a level are bumped by different waves at the same time
+    uint32_t n_nodes;     // inner nodes created
+    int root;             // -1: no items
     uint32_t n_items;
-    uint32_t cur[4];   // the level being processed: tasks, big tasks, small tasks (k_sah_flip: cur = next, next = 0), level
 };
 __device__ __forceinline__ float half_area4(float4 lo, float4 hi) {
     const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
@@ -150,44 +177,44 @@ __global__ void k_sah_init(const uint32_t* count /* device word, or null */, uin
     st->n_items = m;
     st->n_nodes = m != 0u ? m - 1u : 0u;
     st->root = -1;
-    st->n_next = 0u;
-    st->n_next_big = 0u;
-    st->n_next_small = 0u;
+    for (int q = 0; q < 3 * 48; ++q) (&st->cnt[0][0])[q] = 0u;
     if (m >= MPT_SAH_BIG) {
         big_tasks[0] = SahTask{0u, m, -1, 0u, 0u};
-        st->n_next_big = 1u;
+        st->cnt[0][16] = 1u;
     } else if (m >= 2u && m <= MPT_SAH_SMALL) {
         small_tasks[0] = SahTask{0u, m, -1, 0u, 0u};
-        st->n_next_small = 1u;
+        st->cnt[0][32] = 1u;
     } else if (m != 0u) {
         tasks[0] = SahTask{0u, m, -1, 0u, 0u};
-        st->n_next = 1u;
+        st->cnt[0][0] = 1u;
     }
 }
-// Start of a level, one thread: the counts the previous level pushed become the level's own (the kernels of the level read them
-// from the device: their grids are sized from an upper bound, the host does not wait for the counts), the push counters start
-// from zero, and the counts go to a slot of pinned host memory with a stamp behind them — the host reads them one or two
-// levels LATER, to size the grids of the levels it enqueues while the device is busy with this one (run_sah).
-// cover_*: the task counts the host sized this level's grids for (upper bounds, run_sah).  Counts beyond them would be dropped without a
+// Start of a level, ONE thread of the level's first kernel: the set of counts for the level after is zeroed, and the level's own counts go
+// to a slot of pinned host memory with a stamp behind them — the host reads them one or two levels LATER, to size the grids of the levels
+// it enqueues while the device is busy with this one (run_sah).  The kernels of a level read their counts from the device: their grids
+// are sized from an upper bound, the host does not wait for them.
+// cover: the task counts the host sized this level's grids for (upper bounds, run_sah).  Counts beyond them would be dropped without a
 // trace and leave a malformed tree: the stamp then carries MPT_SAH_STAMP_OVERFLOW and the host fails the build.
 #define MPT_SAH_STAMP_OVERFLOW 0x8000u
-__global__ void k_sah_flip(SahState* st, uint32_t level, uint32_t stamp, volatile uint32_t* host_slot, uint32_t cover_mid, uint32_t cover_big, uint32_t cover_small) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t a = st->n_next, b = st->n_next_big, c = st->n_next_small;
-    if (a > cover_mid || b > cover_big || c > cover_small) stamp |= MPT_SAH_STAMP_OVERFLOW;
-    st->cur[0] = a;
-    st->cur[1] = b;
-    st->cur[2] = c;
-    st->cur[3] = level;
-    st->n_next = 0u;
-    st->n_next_big = 0u;
-    st->n_next_small = 0u;
-    host_slot[0] = a;
-    host_slot[1] = b;
-    host_slot[2] = c;
-    __threadfence_system();
-    host_slot[3] = stamp;
-    __threadfence_system();
+struct SahLevel {
+    uint32_t level;
+    uint32_t stamp;                 // 0: this kernel is not the level's first
+    unsigned long long* host_slot;  // three words of pinned host memory, each (stamp << 32 | count)
+    uint32_t cover[3];
+};
+// (every word of the slot carries the stamp itself and is ONE 8-byte store, so nothing has to order the words: no system-scope fence —
+//  a write-back of the whole L2 — in a kernel whose other workgroups are at work)
+__device__ __forceinline__ void sah_level_prologue(SahState* st, const SahLevel& lv) {
+    if (lv.stamp == 0u || threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t* c = st->cnt[lv.level % 3u];
+    uint32_t* z = st->cnt[(lv.level + 2u) % 3u];
+    const uint32_t a = c[0], b = c[16], d = c[32];
+    unsigned long long stamp = lv.stamp;
+    if (a > lv.cover[0] || b > lv.cover[1] || d > lv.cover[2]) stamp |= MPT_SAH_STAMP_OVERFLOW;
+    z[0] = z[16] = z[32] = 0u;
+    __hip_atomic_store(lv.host_slot + 0, stamp << 32 | a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(lv.host_slot + 1, stamp << 32 | b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(lv.host_slot + 2, stamp << 32 | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #define MPT_SAH_WAVES 16   // tasks (waves) per workgroup
 __device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int parent, uint32_t side, int id) {
@@ -198,27 +225,28 @@ __device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int pare
 // a finished split: a single item is attached at once, anything larger becomes a task of the next level.  (Called by SEVERAL
 // lanes of a wave at once where it matters: the counters are uniform addresses, so the compiler turns each atomicAdd into one
 // atomic per wave — 150 k tasks a level each bumping the same three words one by one was 70 % of the builder's time.)
-__device__ __forceinline__ void sah_push_children(SahState* st, int2* s_child, SahTask* next, SahTask* next_big, SahTask* next_small, uint32_t b,
+__device__ __forceinline__ void sah_push_children(uint32_t* push /* st->cnt[(level + 1) % 3] */, int2* s_child, SahTask* next, SahTask* next_big, SahTask* next_small, uint32_t b,
                                                   uint32_t e, uint32_t nlft, uint32_t k, int one_left, int one_right) {
     const uint32_t mid = b + nlft, nrgt = e - mid;
     const SahTask L = SahTask{b, mid, (int)k, 0u, k + 1u}, R = SahTask{mid, e, (int)k, 1u, k + nlft};
     if (nlft == 1u) s_child[k].x = one_left;
-    else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = L;
-    else if (nlft <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = L;
-    else next[atomicAdd(&st->n_next, 1u)] = L;
+    else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&push[16], 1u)] = L;
+    else if (nlft <= MPT_SAH_SMALL) next_small[atomicAdd(&push[32], 1u)] = L;
+    else next[atomicAdd(&push[0], 1u)] = L;
     if (nrgt == 1u) s_child[k].y = one_right;
-    else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&st->n_next_big, 1u)] = R;
-    else if (nrgt <= MPT_SAH_SMALL) next_small[atomicAdd(&st->n_next_small, 1u)] = R;
-    else next[atomicAdd(&st->n_next, 1u)] = R;
+    else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&push[16], 1u)] = R;
+    else if (nrgt <= MPT_SAH_SMALL) next_small[atomicAdd(&push[32], 1u)] = R;
+    else next[atomicAdd(&push[0], 1u)] = R;
 }
-__global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi,
-                                                                  const SahTask* tasks, SahTask* next, SahTask* next_big, SahTask* next_small,
-                                                                  SahState* st, int2* s_child, float4* s_lo, float4* s_hi) {
-    const uint32_t n_tasks = st->cur[0];   // (the grid is sized from an upper bound: waves beyond the count hold an empty task)
+// (a block role of k_sah_tasks below; `block`: the block's number among the level's mid blocks)
+__device__ __forceinline__ void sah_mid_block(uint32_t block, int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
+                                              SahTask* next, SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, float4* s_lo, float4* s_hi,
+                                              uint32_t level) {
+    const uint32_t n_tasks = st->cnt[level % 3u][0];   // (the grid is sized from an upper bound: waves beyond the count hold an empty task)
     __shared__ int bins[MPT_SAH_WAVES][3][16][7];   // per wave: (lo xyz, hi xyz as ordered ints, primitive count) per axis and bin
     __shared__ uint32_t s_push[MPT_SAH_WAVES][6];   // per wave: b, e, nlft, node, first item left / right (e = 0: nothing to push)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x * MPT_SAH_WAVES + wv;
+    const uint32_t t = block * MPT_SAH_WAVES + wv;
     const int TOP = 2 * n - 1;
     SahTask task = SahTask{0u, 0u, -1, 0u, 0u};
     if (t < n_tasks) task = tasks[t];
@@ -363,7 +391,7 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const f
     __syncthreads();
     if (wv == 0 && lane < MPT_SAH_WAVES && s_push[lane][1] != 0u) {
         const uint32_t* P = s_push[lane];
-        sah_push_children(st, s_child, next, next_big, next_small, P[0], P[1], P[2], P[3], (int)P[4], (int)P[5]);
+        sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, P[0], P[1], P[2], P[3], (int)P[4], (int)P[5]);
     }
 }
 
@@ -392,8 +420,9 @@ struct SahBig {
     unsigned long long largest;   // sah_area_key of the item with the largest box
 };
 __device__ __forceinline__ uint32_t sah_chunks(const SahTask& t) { return (t.e - t.b + MPT_SAH_CHUNK - 1u) / MPT_SAH_CHUNK; }
-__global__ __launch_bounds__(1024) void k_big_prep(const SahTask* tasks, const SahState* st, SahBig* big, uint32_t* coff /* [n_big + 1] */) {
-    const uint32_t n_big = st->cur[1];
+__global__ __launch_bounds__(1024) void k_big_prep(const SahTask* tasks, SahState* st, SahBig* big, uint32_t* coff /* [n_big + 1] */, SahLevel lv) {
+    sah_level_prologue(st, lv);
+    const uint32_t n_big = st->cnt[lv.level % 3u][16];
     __shared__ uint32_t s_w[16], s_run;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) s_run = 0u;
@@ -434,8 +463,8 @@ __device__ __forceinline__ uint32_t sah_task_of_chunk(const uint32_t* coff, uint
     return lo;
 }
 __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const float4* in_lo, const float4* in_hi, const SahTask* tasks, const SahState* st,
-                                                                      const uint32_t* coff, SahBig* big) {
-    const uint32_t n_big = st->cur[1];
+                                                                      const uint32_t* coff, SahBig* big, uint32_t level) {
+    const uint32_t n_big = st->cnt[level % 3u][16];
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
     if (c >= coff[n_big]) return;
     const uint32_t t = sah_task_of_chunk(coff, n_big, c);
@@ -490,18 +519,22 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const floa
     if (tid == 12u) atomicMax(&big[t].largest, s_largest);
 }
 __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahBig* big, SahState* st,
-                                                                  int2* s_child, float4* s_lo, float4* s_hi) {
-    __shared__ int bins[3][16][7];
+                                                                  int2* s_child, float4* s_lo, float4* s_hi, uint32_t level) {
+    // (a set of bins per wave, merged afterwards — min, max and sums of integers: the same bins whatever the order; with ONE set the 16
+    //  waves' atomics met on 48 hot addresses and the levels that bin every item of tasks up to 8192 took 76 / 62 / 35 us)
+    constexpr uint32_t NWV = MPT_SAH_BIG_THREADS / 64u;
+    __shared__ int bins_w[NWV][3][16][7];
+    int (*bins)[16][7] = bins_w[0];
     __shared__ float s_cost[48];
     const uint32_t tid = threadIdx.x;
     const int TOP = 2 * n - 1;
-    if (blockIdx.x >= st->cur[1]) return;   // (grid sized from an upper bound)
+    if (blockIdx.x >= st->cnt[level % 3u][16]) return;   // (grid sized from an upper bound)
     const SahTask task = tasks[blockIdx.x];
     SahBig& G = big[blockIdx.x];
     const uint32_t b = task.b, e = task.e, m = e - b;
-    for (uint32_t q = tid; q < 3u * 16u * 7u; q += MPT_SAH_BIG_THREADS) {
+    for (uint32_t q = tid; q < NWV * 3u * 16u * 7u; q += MPT_SAH_BIG_THREADS) {
         const uint32_t f = q % 7u;
-        (&bins[0][0][0])[q] = f < 3u ? 0x7FFFFFFF : f < 6u ? (int)0x80000000 : 0;
+        (&bins_w[0][0][0][0])[q] = f < 3u ? 0x7FFFFFFF : f < 6u ? (int)0x80000000 : 0;
     }
     float cl[3], inv[3];
     for (int a = 0; a < 3; ++a) {
@@ -529,7 +562,7 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
             if (inv[a] == 0.0f) continue;
             int q = (int)((0.5f * (lo3[a] + hi3[a]) - cl[a]) * inv[a]);
             q = q < 0 ? 0 : (q > 15 ? 15 : q);
-            int* B = bins[a][q];
+            int* B = bins_w[tid >> 6][a][q];
             atomicMin(&B[0], f2o(l.x)); atomicMin(&B[1], f2o(l.y)); atomicMin(&B[2], f2o(l.z));
             atomicMax(&B[3], f2o(h.x)); atomicMax(&B[4], f2o(h.y)); atomicMax(&B[5], f2o(h.z));
             atomicAdd(&B[6], cnt);
@@ -537,6 +570,16 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
     };
     for (uint32_t i = b + tid * step; i < e; i += MPT_SAH_BIG_THREADS * step) bin_item(i);
     if (tid == 0 && step > 1u && ((uint32_t)G.largest - b) % step != 0u) bin_item((uint32_t)G.largest);
+    __syncthreads();
+    if (tid < 3u * 16u * 7u) {
+        const uint32_t f = tid % 7u;
+        int v = (&bins_w[0][0][0][0])[tid];
+        for (uint32_t w = 1; w < NWV; ++w) {
+            const int o = (&bins_w[w][0][0][0])[tid];
+            v = f < 3u ? (o < v ? o : v) : f < 6u ? (o > v ? o : v) : v + o;
+        }
+        (&bins_w[0][0][0][0])[tid] = v;
+    }
     __syncthreads();
     if (tid < 48u) {
         float cost = INFINITY;
@@ -597,8 +640,8 @@ __device__ __forceinline__ bool sah_big_left(const SahSplit& s, uint32_t i, floa
     return q <= s.split;
 }
 __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float4* in_lo, const float4* in_hi, const SahTask* tasks, const SahState* st,
-                                                                     const uint32_t* coff, const SahBig* big, uint32_t* chunk_left) {
-    const uint32_t n_big = st->cur[1];
+                                                                     const uint32_t* coff, const SahBig* big, uint32_t* chunk_left, uint32_t level) {
+    const uint32_t n_big = st->cnt[level % 3u][16];
     __shared__ uint32_t s_w[MPT_SAH_CHUNK_THREADS / 64u];
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (c >= coff[n_big]) return;
@@ -618,8 +661,8 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_count(const float
     }
 }
 __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
-                                                                       const SahState* st, const uint32_t* coff, SahBig* big, const uint32_t* chunk_left) {
-    const uint32_t n_big = st->cur[1];
+                                                                       const SahState* st, const uint32_t* coff, SahBig* big, const uint32_t* chunk_left, uint32_t level) {
+    const uint32_t n_big = st->cnt[level % 3u][16];
     constexpr uint32_t NW = MPT_SAH_CHUNK_THREADS / 64u;
     __shared__ uint32_t s_wl[NW], s_wr[NW], s_before[NW];
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -674,13 +717,13 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const flo
         __syncthreads();
     }
 }
-__global__ void k_big_push(const SahTask* tasks, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
-                           SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= st->cur[1]) return;
+// (a block role of k_sah_tasks below: it needs the level's k_big_count, nothing of its mid and small tasks)
+__device__ __forceinline__ void sah_big_push_thread(uint32_t t, const SahTask* tasks, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
+                                                    SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, uint32_t level) {
+    if (t >= st->cnt[level % 3u][16]) return;
     uint32_t nlft = 0;
     for (uint32_t c = coff[t]; c < coff[t + 1u]; ++c) nlft += chunk_left[c];
-    sah_push_children(st, s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1]);
+    sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1]);
 }
 
 // ... and for a SMALL task (<= MPT_SAH_SMALL items: the last three or four levels, which hold most of the tree's nodes and took
@@ -689,12 +732,12 @@ __global__ void k_big_push(const SahTask* tasks, const uint32_t* coff, const Sah
 // shuffles, the partition by ds_permute), so no task of the bottom levels is ever queued.  Same algorithm and same choices as
 // k_sah_level (16 bins over the box centres, cost = area * primitives, ties to the lowest (axis, split)); a lane prices the
 // three planes behind its own item's bins, which are all the planes that separate anything.
-__global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahState* st,
-                                                   int2* s_child, float4* s_lo, float4* s_hi) {
-    const uint32_t n_tasks = st->cur[2];   // (the grid is sized from an upper bound)
+__device__ __forceinline__ void sah_small_thread(uint32_t thread /* among the level's small-task threads */, int n, const float4* in_lo, const float4* in_hi,
+                                                 const SahTask* tasks, SahState* st, int2* s_child, float4* s_lo, float4* s_hi, uint32_t level) {
+    const uint32_t n_tasks = st->cnt[level % 3u][32];   // (the grid is sized from an upper bound)
     constexpr uint32_t G = MPT_SAH_SMALL;
     static_assert(G == 8u || G == 16u, "MPT_SAH_SMALL: 8 or 16");
-    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / G, lane = threadIdx.x & 63u, gl = lane & (G - 1u), gbase = lane & ~(G - 1u);
+    const uint32_t t = thread / G, lane = threadIdx.x & 63u, gl = lane & (G - 1u), gbase = lane & ~(G - 1u);
     const int TOP = 2 * n - 1;
     SahTask task = SahTask{0u, 0u, -1, 0u, 0u};
     if (t < n_tasks) task = tasks[t];
@@ -837,6 +880,38 @@ __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, c
     }
 }
 
+// The three kinds of per-task work of a level that need nothing of one another, in ONE launch while the level has big tasks (until round 4:
+// three — and in the levels with big tasks there are few tasks of the other kinds or none, so two of them ran nearly empty grids):
+// blocks [0, mid_blocks) split the level's mid tasks, a wave each; [mid_blocks, + small_blocks) finish its small tasks; the rest push the
+// children of its big tasks (whose partition the kernels before this one made).  The mid blocks come first: they run longest.
+__global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_tasks(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
+                                                                  const SahTask* small_tasks, const SahTask* big_tasks, SahTask* next, SahTask* next_big,
+                                                                  SahTask* next_small, SahState* st, int2* s_child, float4* s_lo, float4* s_hi, const uint32_t* coff,
+                                                                  const SahBig* big, const uint32_t* chunk_left, uint32_t mid_blocks, uint32_t small_blocks, SahLevel lv) {
+    sah_level_prologue(st, lv);
+    if (blockIdx.x < mid_blocks)
+        sah_mid_block(blockIdx.x, n, in_lo, in_hi, out_lo, out_hi, tasks, next, next_big, next_small, st, s_child, s_lo, s_hi, lv.level);
+    else if (blockIdx.x < mid_blocks + small_blocks)
+        sah_small_thread((blockIdx.x - mid_blocks) * (64u * MPT_SAH_WAVES) + threadIdx.x, n, in_lo, in_hi, small_tasks, st, s_child, s_lo, s_hi, lv.level);
+    else
+        sah_big_push_thread((blockIdx.x - mid_blocks - small_blocks) * (64u * MPT_SAH_WAVES) + threadIdx.x, big_tasks, coff, big, chunk_left, next, next_big, next_small, st,
+                            s_child, lv.level);
+}
+
+// ... and the mid and the small tasks on their own, for the levels that have no big task any more (most of the tree's nodes are made there:
+// in one kernel the two kinds of blocks ran 20 % slower than one after the other, 1060 against 885 us for the last ten levels of 1 M items)
+__global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
+                                                                  SahTask* next, SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, float4* s_lo,
+                                                                  float4* s_hi, SahLevel lv) {
+    sah_level_prologue(st, lv);
+    sah_mid_block(blockIdx.x, n, in_lo, in_hi, out_lo, out_hi, tasks, next, next_big, next_small, st, s_child, s_lo, s_hi, lv.level);
+}
+__global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahState* st, int2* s_child, float4* s_lo,
+                                                   float4* s_hi, SahLevel lv) {
+    sah_level_prologue(st, lv);
+    sah_small_thread(blockIdx.x * blockDim.x + threadIdx.x, n, in_lo, in_hi, tasks, st, s_child, s_lo, s_hi, lv.level);
+}
+
 struct SahTree {
     int2* child = nullptr;
     float4 *lo = nullptr, *hi = nullptr;
@@ -846,9 +921,9 @@ struct SahTree {
 // is *d_count if d_count is not null (a device word), else count_host; max_items bounds it.  pin: >= 1 KiB of pinned host memory.
 //
 // No host wait inside the level loop (round 4; round 3 synchronised the stream once per level to read three counters: ~22 idle
-// gaps of 30-40 us for 1 M items).  The kernels of a level read their task counts from the device (SahState::cur, k_sah_flip) and
+// gaps of 30-40 us for 1 M items).  The kernels of a level read their task counts from the device (SahState::cnt, sah_level_prologue) and
 // are launched on grids sized from an UPPER BOUND — a level at most doubles the number of tasks, so the bound comes from the
-// exact counts of one or two levels before, which k_sah_flip left in pinned memory with a stamp.  The host only ever waits for a
+// exact counts of one or two levels before, which the level's first kernel left in pinned memory with a stamp.  The host only ever waits for a
 // level the device has already passed (or is about to): the device always has the next level queued.  The loop ends one or two
 // (empty) levels late; waves and workgroups beyond the true counts return at once.
 static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int top, const uint32_t* d_count, uint32_t count_host, uint32_t max_items,
@@ -875,33 +950,39 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
     MPT_LB(sc.alloc(&T.hi, max_items));
     // (k_sah_* take n with top = 2n - 1)
     const int n = (top + 1) / 2;
-    // eight slots of (tasks, big, small, stamp) in pinned memory, behind the words other read-backs of the build use
+    // eight slots of three 8-byte words (stamp << 32 | mid tasks, big tasks, small tasks) in pinned memory, behind the words other read-backs
+    // of the build use
     static uint32_t s_epoch = 0;
-    const uint32_t epoch = (++s_epoch & 0xFFFFu) << 16;
-    volatile uint32_t* slots = pin + 64;
-    uint32_t* d_pin = nullptr;
-    MPT_LB(hipHostGetDevicePointer((void**)&d_pin, pin, 0));
-    for (int q = 0; q < 8; ++q) slots[4 * q + 3] = 0u;
+    const uint32_t epoch = (++s_epoch & 0x7FFFu) << 16;
+    volatile unsigned long long* slots = (volatile unsigned long long*)(pin + 64);
+    unsigned long long* d_slots = nullptr;
+    MPT_LB(hipHostGetDevicePointer((void**)&d_slots, pin + 64, 0));
+    for (int q = 0; q < 24; ++q) slots[q] = 0ull;
     hipLaunchKernelGGL(k_sah_init, dim3(1), dim3(64), 0, stream, d_count, count_host, T.st, tasks_a, big_a, small_a);
     const uint32_t cap_mid = max_items / (MPT_SAH_SMALL + 1u) + 2u, cap_small = max_items / 2u + 2u;
-    auto wait_slot = [&](int level, uint32_t out[3]) -> hipError_t {   // the counts of `level`, once k_sah_flip(level) has run
-        volatile uint32_t* sl = slots + 4 * (level & 7);
+    auto slot_ready = [&](int level) {   // all three words of the level's slot carry its stamp
+        volatile unsigned long long* sl = slots + 3 * (level & 7);
         const uint32_t want = epoch | (uint32_t)(level + 1);
+        for (int q = 0; q < 3; ++q)
+            if (((uint32_t)(sl[q] >> 32) & ~MPT_SAH_STAMP_OVERFLOW) != want) return false;
+        return true;
+    };
+    auto wait_slot = [&](int level, uint32_t out[3]) -> hipError_t {   // the counts of `level`, once its first kernel has started
+        volatile unsigned long long* sl = slots + 3 * (level & 7);
         const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned long long spin = 0;; ++spin) {
-            const uint32_t seen = sl[3];
-            if (seen == want) break;
-            if (seen == (want | MPT_SAH_STAMP_OVERFLOW)) return hipErrorLaunchOutOfResources;   // a level had more tasks than its grids covered (k_sah_flip)
+        for (unsigned long long spin = 0; !slot_ready(level); ++spin) {
             if ((spin & 0xFFFu) == 0xFFFu) {
                 const hipError_t q = hipStreamQuery(stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return q;
-                if (q == hipSuccess && (sl[3] & ~MPT_SAH_STAMP_OVERFLOW) != want) return hipErrorUnknown;   // the stream is drained and the stamp never came
+                if (q == hipSuccess && !slot_ready(level)) return hipErrorUnknown;   // the stream is drained and the stamp never came
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return hipErrorLaunchTimeOut;   // (a level takes < 1 ms: a kernel hangs)
             }
         }
-        out[0] = sl[0];
-        out[1] = sl[1];
-        out[2] = sl[2];
+        unsigned long long w[3] = {sl[0], sl[1], sl[2]};
+        for (int q = 0; q < 3; ++q) {
+            if ((uint32_t)(w[q] >> 32) & MPT_SAH_STAMP_OVERFLOW) return hipErrorLaunchOutOfResources;   // a level had more tasks than its grids covered (sah_level_prologue)
+            out[q] = (uint32_t)w[q];
+        }
         return hipSuccess;
     };
     uint32_t b_mid = 1u, b_big = 1u, b_small = 1u;   // upper bounds of the level about to be enqueued (level 0: the root task, of one kind)
@@ -909,34 +990,47 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
     bool done = false;
     int level = 0;
     for (; level < 4096 && !done; ++level) {
-        hipLaunchKernelGGL(k_sah_flip, dim3(1), dim3(64), 0, stream, T.st, (uint32_t)level, epoch | (uint32_t)(level + 1), (volatile uint32_t*)(d_pin + 64 + 4 * (level & 7)),
-                           b_mid, b_big, b_small);
+        // (the level's first kernel publishes its counts and zeroes the set of the level after: sah_level_prologue)
+        SahLevel first = {(uint32_t)level, epoch | (uint32_t)(level + 1), d_slots + 3 * (level & 7), {b_mid, b_big, b_small}};
+        const SahLevel rest = {(uint32_t)level, 0u, nullptr, {0u, 0u, 0u}};
+        auto take = [&]() {   // the prologue goes to whichever kernel is launched first
+            const SahLevel r = first;
+            first = rest;
+            return r;
+        };
+        const uint32_t lvl = (uint32_t)level;
         if (b_big) {
             const uint32_t chunks = max_items / MPT_SAH_CHUNK + b_big;   // >= sum of ceil(items / chunk) over the level's big tasks
-            hipLaunchKernelGGL(k_big_prep, dim3(1), dim3(1024), 0, stream, (const SahTask*)big_a, (const SahState*)T.st, bigs, coff);
+            hipLaunchKernelGGL(k_big_prep, dim3(1), dim3(1024), 0, stream, (const SahTask*)big_a, T.st, bigs, coff, take());
             hipLaunchKernelGGL(k_big_bounds, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
-                               (const SahState*)T.st, (const uint32_t*)coff, bigs);
+                               (const SahState*)T.st, (const uint32_t*)coff, bigs, lvl);
             hipLaunchKernelGGL(k_big_pick, dim3(b_big), dim3(MPT_SAH_BIG_THREADS), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a, bigs,
-                               T.st, T.child, T.lo, T.hi);
+                               T.st, T.child, T.lo, T.hi, lvl);
             hipLaunchKernelGGL(k_big_count, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
-                               (const SahState*)T.st, (const uint32_t*)coff, (const SahBig*)bigs, chunk_left);
+                               (const SahState*)T.st, (const uint32_t*)coff, (const SahBig*)bigs, chunk_left, lvl);
             hipLaunchKernelGGL(k_big_scatter, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b, it_hi_b,
-                               (const SahTask*)big_a, (const SahState*)T.st, (const uint32_t*)coff, bigs, (const uint32_t*)chunk_left);
-            hipLaunchKernelGGL(k_big_push, dim3((b_big + 255u) / 256u), dim3(256), 0, stream, (const SahTask*)big_a, (const uint32_t*)coff, (const SahBig*)bigs,
-                               (const uint32_t*)chunk_left, tasks_b, big_b, small_b, T.st, T.child);
+                               (const SahTask*)big_a, (const SahState*)T.st, (const uint32_t*)coff, bigs, (const uint32_t*)chunk_left, lvl);
+            // ... and ONE launch for the children of the big tasks and the level's mid and small tasks (k_sah_tasks)
+            constexpr uint32_t TH = 64u * MPT_SAH_WAVES;
+            const uint32_t mid_blocks = (b_mid + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES, small_blocks = (uint32_t)(((size_t)b_small * MPT_SAH_SMALL + TH - 1) / TH),
+                           push_blocks = (b_big + TH - 1) / TH;
+            hipLaunchKernelGGL(k_sah_tasks, dim3(mid_blocks + small_blocks + push_blocks), dim3(TH), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b,
+                               it_hi_b, (const SahTask*)tasks_a, (const SahTask*)small_a, (const SahTask*)big_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi,
+                               (const uint32_t*)coff, (const SahBig*)bigs, (const uint32_t*)chunk_left, mid_blocks, small_blocks, take());
+        } else {
+            if (b_mid)
+                hipLaunchKernelGGL(k_sah_level, dim3((b_mid + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES), dim3(64 * MPT_SAH_WAVES), 0, stream, n, (const float4*)it_lo_a,
+                                   (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi, take());
+            if (b_small || first.stamp != 0u)   // (a level with no grid at all still publishes its counts: zeroes, which end the loop)
+                hipLaunchKernelGGL(k_sah_small, dim3((uint32_t)(((size_t)std::max(b_small, 1u) * MPT_SAH_SMALL + 255) / 256)), dim3(256), 0, stream, n, (const float4*)it_lo_a,
+                                   (const float4*)it_hi_a, (const SahTask*)small_a, T.st, T.child, T.lo, T.hi, take());
         }
-        if (b_mid)
-            hipLaunchKernelGGL(k_sah_level, dim3((b_mid + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES), dim3(64 * MPT_SAH_WAVES), 0, stream, n, (const float4*)it_lo_a,
-                               (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi);
-        if (b_small)
-            hipLaunchKernelGGL(k_sah_small, dim3((uint32_t)(((size_t)b_small * MPT_SAH_SMALL + 255) / 256)), dim3(256), 0, stream, n, (const float4*)it_lo_a,
-                               (const float4*)it_hi_a, (const SahTask*)small_a, T.st, T.child, T.lo, T.hi);
         MPT_LB(hipGetLastError());
         // bounds of level + 1 from the newest exact counts: those of level - 1 at the latest (the device is past them or about to
         // be: the wait is short and the device keeps `level` in its queue meanwhile), those of `level` if they are there already
         uint32_t c[3];
         int from = level - 1;
-        if (slots[4 * (level & 7) + 3] == (epoch | (uint32_t)(level + 1))) from = level;
+        if (slot_ready(level)) from = level;
         if (from >= 0) {
             MPT_LB(wait_slot(from, c));
             known = from;
