@@ -35,6 +35,7 @@ struct Scalars {             // device-side results the host reads back once, at
     uint32_t n_mats;
     uint32_t n_leaves;
     uint32_t n_acc_nodes, acc_depth;
+    uint32_t odd_leaf;       // a leaf without a sphere has an empty (NaN) own box: the own tree is then refitted bottom-up (k_own_tree), not copied
     uint32_t mat_collision;  // two different materials with the same 32-bit sort key were seen (build() then sorts on all 64 bits)
 };
 
@@ -200,6 +201,7 @@ __global__ void k_leaves(int n, int leaf_max, const int2* range, const uint32_t*
     }
     olo[node] = bl;
     ohi[node] = bh;
+    if (nsph == 0 && empty4(bl, bh)) sc->odd_leaf = 1u;
 }
 // ---- the threaded reference-order tree --------------------------------------------------------------------------------------
 // depth of every output node and its skip link: the node the reference visits after this node's subtree.  The reference
@@ -275,9 +277,10 @@ using mpt_lbvh::st_agent;
 //  s_waitcnt vmcnt(0) in front of the arrival counter)
 using mpt_lbvh::handoff_release;
 __global__ void k_own_tree(int n, const int* parent, const int2* child, const uint32_t* is_leaf, const float4* olo, const float4* ohi, int* eff, float4* s_lo,
-                           float4* s_hi, int2* s_child, int* arrived, SahState* st) {
+                           float4* s_hi, int2* s_child, int* arrived, SahState* st, const Scalars* skip_unless_odd) {
     const int leaf = blockIdx.x * blockDim.x + threadIdx.x, TOP = 2 * n - 1;
     if (leaf >= TOP || !is_leaf[leaf]) return;
+    if (skip_unless_odd && !skip_unless_odd->odd_leaf) return;   // (k_own_copy + k_own_chain have made the tree)
     int e = empty4(olo[leaf], ohi[leaf]) ? -1 : leaf;
     st_agent(&eff[leaf], e);
     int cur = leaf;
@@ -305,6 +308,67 @@ __global__ void k_own_tree(int n, const int* parent, const int2* child, const ui
         st_agent(&eff[p], e);
         cur = p;
     }
+}
+
+// The common case of the above needs no walk (round 5; the walk is a chain of ~40 dependent atomics per leaf, 180 us for 1 M primitives):
+// with the spheres hoisted, no leaf below the SAH's root holds one, so every such leaf's own box IS its reference box, and unless a leaf is
+// empty (triangles with NaN corners: Scalars::odd_leaf) every inner node has two non-empty children — its box is the node box the builder
+// already has (minima and maxima are exact, whatever the order), its children are its children.  k_own_copy writes that for every inner node
+// at once; k_own_chain then redoes the root and the <= 15 chain nodes that hold the hoisted items — whose leaves ARE empty where they hold a
+// sphere — with the rule of k_own_tree, one thread, top of the tree only.  Same arrays as the walk, entry for entry, where the collapse reads.
+__global__ void k_own_copy(int n, const int2* child, const uint32_t* keep, const uint32_t* is_leaf, const float4* nlo, const float4* nhi, const Scalars* sc, float4* s_lo,
+                           float4* s_hi, int2* s_child) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, TOP = 2 * n - 1;
+    if (p >= n - 1 || sc->odd_leaf || !keep[p] || is_leaf[p]) return;
+    const int2 c = child[p];
+    const float4 l = nlo[p], h = nhi[p];
+    s_lo[p] = make_float4(l.x, l.y, l.z, 0.0f);
+    s_hi[p] = make_float4(h.x, h.y, h.z, 0.0f);
+    s_child[p] = make_int2(is_leaf[c.x] ? c.x : TOP + c.x, is_leaf[c.y] ? c.y : TOP + c.y);
+}
+__global__ void k_own_chain(int n, int n_hoisted, const int2* child, const uint32_t* is_leaf, const float4* olo, const float4* ohi, const Scalars* sc, float4* s_lo,
+                            float4* s_hi, int2* s_child, SahState* st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || sc->odd_leaf) return;
+    const int TOP = 2 * n - 1;
+    // the root and the chain below it, top-down: node[0] = the root, node[j] = child[node[j - 1]].x while that is a chain node
+    int node[17];
+    int m = 0;
+    node[m++] = 0;
+    if (n_hoisted >= 1 && !is_leaf[0]) {
+        int c = child[0].x;
+        for (int j = 1; j < n_hoisted && !is_leaf[c]; ++j) {
+            node[m++] = c;
+            c = child[c].y;
+        }
+    }
+    // the sub-tree that stands for a node (k_own_tree's eff): bottom-up over the chain; everything else is as k_own_copy left it
+    auto eff_of = [&](int id, const int* eff_chain) -> int {
+        if (is_leaf[id]) return empty4(olo[id], ohi[id]) ? -1 : id;
+        for (int j = 0; j < m; ++j)
+            if (node[j] == id) return eff_chain[j];
+        return TOP + id;
+    };
+    int eff_chain[17];
+    for (int j = m - 1; j >= 0; --j) {
+        const int p = node[j];
+        if (is_leaf[p]) {   // (a tree whose root is a leaf)
+            eff_chain[j] = empty4(olo[p], ohi[p]) ? -1 : p;
+            continue;
+        }
+        const int2 c = child[p];
+        const int ex = eff_of(c.x, eff_chain), ey = eff_of(c.y, eff_chain);
+        if (ex >= 0 && ey >= 0) {
+            const float4 a0 = ex < TOP ? olo[ex] : s_lo[ex - TOP], a1 = ex < TOP ? ohi[ex] : s_hi[ex - TOP];
+            const float4 b0 = ey < TOP ? olo[ey] : s_lo[ey - TOP], b1 = ey < TOP ? ohi[ey] : s_hi[ey - TOP];
+            s_lo[p] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.0f);
+            s_hi[p] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.0f);
+            s_child[p] = make_int2(ex, ey);
+            eff_chain[j] = TOP + p;
+        } else {
+            eff_chain[j] = ex >= 0 ? ex : ey;
+        }
+    }
+    st->root = eff_chain[0];
 }
 
 // ---- the own 4-wide tree: breadth-first collapse of the SAH tree, level by level -----------------------------------------------
@@ -671,8 +735,17 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         MPT_LB(sc.alloc(&s_hi, n));
         MPT_LB(hipMemsetAsync(arrived, 0, nn * 4, stream));
         MPT_LB(hipMemsetAsync(d_st, 0xFF, sizeof(SahState), stream));   // root = -1
+        // (the copy is valid when every leaf's own box is its reference box or, in the chain of hoisted items, empty: spheres hoisted or none
+        //  — with spheres INSIDE the SAH's leaves and no always list the boxes agree too, but then nothing marks the chain: the walk)
+        const bool fast = (R.spheres_hoisted || n_spheres_hint == 0) && getenv("MPT_OWN_TREE_WALK") == nullptr;
+        if (fast) {
+            hipLaunchKernelGGL(k_own_copy, dim3((n + B - 1) / B), dim3(B), 0, stream, (int)n, (const int2*)R.child, (const uint32_t*)R.keep, (const uint32_t*)is_leaf,
+                               (const float4*)R.nlo, (const float4*)R.nhi, (const Scalars*)d_sc, s_lo, s_hi, s_child);
+            hipLaunchKernelGGL(k_own_chain, dim3(1), dim3(64), 0, stream, (int)n, (int)R.n_hoisted, (const int2*)R.child, (const uint32_t*)is_leaf, (const float4*)olo,
+                               (const float4*)ohi, (const Scalars*)d_sc, s_lo, s_hi, s_child, d_st);
+        }
         hipLaunchKernelGGL(k_own_tree, dim3(gnn), dim3(B), 0, stream, (int)n, (const int*)R.parent, (const int2*)R.child, (const uint32_t*)is_leaf, (const float4*)olo,
-                           (const float4*)ohi, eff, s_lo, s_hi, s_child, arrived, d_st);
+                           (const float4*)ohi, eff, s_lo, s_hi, s_child, arrived, d_st, fast ? (const Scalars*)d_sc : (const Scalars*)nullptr);
     } else {
         uint32_t *flag_pos, *rank;
         float4 *it_lo_a, *it_hi_a;

@@ -375,11 +375,14 @@ __global__ void k_prim_items(int n, const float4* blo, const float4* bhi, float4
 }
 // ... and its tree (inner node k = SAH node k, made top-down: parents before children, the root first) in the arrays the
 // clustering leaves: children, parents, primitives below every node, boxes
-__global__ void k_sah_to_radix(int n, const int2* s_child, const float4* s_lo, const float4* s_hi, const float4* blo, const float4* bhi, int2* child, int* parent,
-                               uint32_t* size, float4* nlo, float4* nhi) {
+// first[node]: the depth-first position of the node's first primitive (k_ploc_first), here straight from the SAH, which knows where every
+// node's items start in its final item order (mpt_sah.h SahFirst)
+__global__ void k_sah_to_radix(int n, const int2* s_child, const float4* s_lo, const float4* s_hi, const float4* blo, const float4* bhi, const uint32_t* first_inner,
+                               const uint32_t* first_item, int2* child, int* parent, uint32_t* size, float4* nlo, float4* nhi, uint32_t* first) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x, top = 2 * n - 1;
     if (node >= top) return;
     if (node == 0) parent[0] = -1;
+    first[node] = node < n - 1 ? first_inner[node] : first_item[node];
     if (node < n - 1) {
         const int2 c = s_child[node];
         const int x = c.x >= top ? c.x - top : c.x, y = c.y >= top ? c.y - top : c.y;
@@ -482,10 +485,18 @@ __global__ void k_prim_items_hoisted(int n, const float4* blo, const float4* bhi
     }
 }
 __global__ void k_sah_to_radix_hoisted(int n, int ns, const int2* s_child, const float4* s_lo, const float4* s_hi, const float4* blo, const float4* bhi,
-                                       const uint32_t* sph, int2* child, int* parent, uint32_t* size, float4* nlo, float4* nhi) {
+                                       const uint32_t* sph, const uint32_t* flag, const uint32_t* rank, const uint32_t* first_inner, const uint32_t* first_item,
+                                       int2* child, int* parent, uint32_t* size, float4* nlo, float4* nhi, uint32_t* first) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x, top = 2 * n - 1;
     if (node >= top) return;
     if (node == 0) parent[0] = -1;
+    // depth-first order: the hoisted items (the chain under the root, in their order), then the SAH's items in its final item order
+    if (node >= n - 1) {
+        const int p = node - (n - 1);
+        first[node] = flag[p] ? (uint32_t)ns + first_item[node] : (uint32_t)p - rank[p];
+    } else {
+        first[node] = node >= ns ? (uint32_t)ns + first_inner[node - ns] : node == 0 ? 0u : (uint32_t)(node - 1);
+    }
     if (node >= n - 1) {   // a primitive
         size[node] = 1u;
         nlo[node] = blo[node - (n - 1)];
@@ -549,6 +560,7 @@ struct Radix {
     int *cb = nullptr;                       // centroid bounds (ordered ints)
     uint32_t n_out = 0;                      // output nodes (read back)
     bool spheres_hoisted = false;            // builder "sah": the spheres hang under the root, the SAH nodes hold triangles only
+    uint32_t n_hoisted = 0;                  // ... how many items hang there (spheres and huge triangles: a chain of n_hoisted - 1 nodes under the root)
 };
 
 // the output nodes of a finished tree: flags, compact index, count (one stream synchronisation for the count)
@@ -641,20 +653,25 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
         MPT_LB(hipStreamSynchronize(stream));
         const uint32_t nt = pinned.p[0], ns = n - nt;
         mpt_sah::SahTree T;
+        uint32_t *first_inner, *first_item;
+        MPT_LB(sc.alloc(&first_inner, n));
+        MPT_LB(sc.alloc(&first_item, nn));
+        T.first = mpt_sah::SahFirst{first_inner, first_item};
         if (ns >= 1u && ns <= MPT_LBVH_HOIST_MAX && nt >= 3u && getenv("MPT_SAH_KEEP_SPHERES") == nullptr) {
             R.spheres_hoisted = true;
+            R.n_hoisted = ns;
             hipLaunchKernelGGL(k_prim_items_hoisted, dim3(gn), dim3(B), 0, stream, (int)n, (const float4*)R.blo, (const float4*)R.bhi, (const uint32_t*)flag,
                                (const uint32_t*)rank, it_lo, it_hi, vals0, sph);
             MPT_LB(mpt_sah::run_sah(stream, sc, pinned.p, (int)nn, nullptr, nt, nt, it_lo, it_hi, T));
             hipLaunchKernelGGL(k_sah_to_radix_hoisted, dim3(gnn), dim3(B), 0, stream, (int)n, (int)ns, (const int2*)T.child, (const float4*)T.lo, (const float4*)T.hi,
-                               (const float4*)R.blo, (const float4*)R.bhi, (const uint32_t*)sph, child0, parent0, size, nlo0, nhi0);
+                               (const float4*)R.blo, (const float4*)R.bhi, (const uint32_t*)sph, (const uint32_t*)flag, (const uint32_t*)rank, (const uint32_t*)first_inner,
+                               (const uint32_t*)first_item, child0, parent0, size, nlo0, nhi0, first);
         } else {
             hipLaunchKernelGGL(k_prim_items, dim3(gn), dim3(B), 0, stream, (int)n, (const float4*)R.blo, (const float4*)R.bhi, it_lo, it_hi, vals0);
             MPT_LB(mpt_sah::run_sah(stream, sc, pinned.p, (int)nn, nullptr, n, n, it_lo, it_hi, T));
             hipLaunchKernelGGL(k_sah_to_radix, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)T.child, (const float4*)T.lo, (const float4*)T.hi, (const float4*)R.blo,
-                               (const float4*)R.bhi, child0, parent0, size, nlo0, nhi0);
+                               (const float4*)R.bhi, (const uint32_t*)first_inner, (const uint32_t*)first_item, child0, parent0, size, nlo0, nhi0, first);
         }
-        hipLaunchKernelGGL(k_ploc_first, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size, first);
         hipLaunchKernelGGL(k_ploc_renumber<true>, dim3(gnn), dim3(B), 0, stream, (int)n, (const int2*)child0, (const int*)parent0, (const uint32_t*)size,
                            (const uint32_t*)first, (const float4*)nlo0, (const float4*)nhi0, (const uint32_t*)vals0, R.child, R.parent, R.range, R.nlo, R.nhi, R.vals);
         return finish_radix(stream, sc, R, pinned.p);

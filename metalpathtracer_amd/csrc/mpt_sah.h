@@ -217,6 +217,12 @@ __device__ __forceinline__ void sah_level_prologue(SahState* st, const SahLevel&
     __hip_atomic_store(lv.host_slot + 2, stamp << 32 | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #define MPT_SAH_WAVES 16   // tasks (waves) per workgroup
+// Where a node's items start in the final item order (the order the partitions leave: left sub-tree first) — known the moment the node is
+// made, or an item is left alone: inner[k] for inner node k, item[id] for an item.  Either may be null.  (mpt_lbvh.h numbers the nodes of
+// the reference-format tree by these; until round 5 a kernel of its own walked from every node to the root to find them, 105 us for 1 M.)
+struct SahFirst {
+    uint32_t *inner, *item;
+};
 __device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int parent, uint32_t side, int id) {
     if (parent < 0) st->root = id;
     else if (side == 0u) s_child[parent].x = id;
@@ -226,22 +232,26 @@ __device__ __forceinline__ void sah_attach(SahState* st, int2* s_child, int pare
 // lanes of a wave at once where it matters: the counters are uniform addresses, so the compiler turns each atomicAdd into one
 // atomic per wave — 150 k tasks a level each bumping the same three words one by one was 70 % of the builder's time.)
 __device__ __forceinline__ void sah_push_children(uint32_t* push /* st->cnt[(level + 1) % 3] */, int2* s_child, SahTask* next, SahTask* next_big, SahTask* next_small, uint32_t b,
-                                                  uint32_t e, uint32_t nlft, uint32_t k, int one_left, int one_right) {
+                                                  uint32_t e, uint32_t nlft, uint32_t k, int one_left, int one_right, const SahFirst& fs) {
     const uint32_t mid = b + nlft, nrgt = e - mid;
     const SahTask L = SahTask{b, mid, (int)k, 0u, k + 1u}, R = SahTask{mid, e, (int)k, 1u, k + nlft};
-    if (nlft == 1u) s_child[k].x = one_left;
-    else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&push[16], 1u)] = L;
+    if (nlft == 1u) {
+        s_child[k].x = one_left;
+        if (fs.item) fs.item[one_left] = b;
+    } else if (nlft >= MPT_SAH_BIG) next_big[atomicAdd(&push[16], 1u)] = L;
     else if (nlft <= MPT_SAH_SMALL) next_small[atomicAdd(&push[32], 1u)] = L;
     else next[atomicAdd(&push[0], 1u)] = L;
-    if (nrgt == 1u) s_child[k].y = one_right;
-    else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&push[16], 1u)] = R;
+    if (nrgt == 1u) {
+        s_child[k].y = one_right;
+        if (fs.item) fs.item[one_right] = e - 1u;
+    } else if (nrgt >= MPT_SAH_BIG) next_big[atomicAdd(&push[16], 1u)] = R;
     else if (nrgt <= MPT_SAH_SMALL) next_small[atomicAdd(&push[32], 1u)] = R;
     else next[atomicAdd(&push[0], 1u)] = R;
 }
 // (a block role of k_sah_tasks below; `block`: the block's number among the level's mid blocks)
 __device__ __forceinline__ void sah_mid_block(uint32_t block, int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
                                               SahTask* next, SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, float4* s_lo, float4* s_hi,
-                                              uint32_t level) {
+                                              uint32_t level, const SahFirst& fs) {
     const uint32_t n_tasks = st->cnt[level % 3u][0];   // (the grid is sized from an upper bound: waves beyond the count hold an empty task)
     __shared__ int bins[MPT_SAH_WAVES][3][16][7];   // per wave: (lo xyz, hi xyz as ordered ints, primitive count) per axis and bin
     __shared__ uint32_t s_push[MPT_SAH_WAVES][6];   // per wave: b, e, nlft, node, first item left / right (e = 0: nothing to push)
@@ -252,8 +262,11 @@ __device__ __forceinline__ void sah_mid_block(uint32_t block, int n, const float
     if (t < n_tasks) task = tasks[t];
     const uint32_t b = task.b, e = task.e, m = e - b;
     if (lane == 0) s_push[wv][1] = 0u;
-    if (m == 1u && lane == 0)   // (only the root task of a one-leaf tree: children of one item are attached when they are split off)
-        sah_attach(st, s_child, task.parent, task.side, __float_as_int(in_lo[b].w));
+    if (m == 1u && lane == 0) {   // (only the root task of a one-leaf tree: children of one item are attached when they are split off)
+        const int id = __float_as_int(in_lo[b].w);
+        sah_attach(st, s_child, task.parent, task.side, id);
+        if (fs.item) fs.item[id] = b;
+    }
     if (m >= 2u) {
     // pass 1: the node's box and the bounds of the box centres
     float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
@@ -286,6 +299,7 @@ __device__ __forceinline__ void sah_mid_block(uint32_t block, int n, const float
     const uint32_t k = task.node;
     if (lane == 0) {
         s_lo[k] = make_float4(nl[0], nl[1], nl[2], __int_as_float((int)m));   // (.w: items below the node)
+        if (fs.inner) fs.inner[k] = b;
         s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
         sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
     }
@@ -391,7 +405,7 @@ __device__ __forceinline__ void sah_mid_block(uint32_t block, int n, const float
     __syncthreads();
     if (wv == 0 && lane < MPT_SAH_WAVES && s_push[lane][1] != 0u) {
         const uint32_t* P = s_push[lane];
-        sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, P[0], P[1], P[2], P[3], (int)P[4], (int)P[5]);
+        sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, P[0], P[1], P[2], P[3], (int)P[4], (int)P[5], fs);
     }
 }
 
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_bounds(const floa
     if (tid == 12u) atomicMax(&big[t].largest, s_largest);
 }
 __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahBig* big, SahState* st,
-                                                                  int2* s_child, float4* s_lo, float4* s_hi, uint32_t level) {
+                                                                  int2* s_child, float4* s_lo, float4* s_hi, uint32_t level, SahFirst fs) {
     // (a set of bins per wave, merged afterwards — min, max and sums of integers: the same bins whatever the order; with ONE set the 16
     //  waves' atomics met on 48 hot addresses and the levels that bin every item of tasks up to 8192 took 76 / 62 / 35 us)
     constexpr uint32_t NWV = MPT_SAH_BIG_THREADS / 64u;
@@ -547,6 +561,7 @@ __global__ __launch_bounds__(MPT_SAH_BIG_THREADS) void k_big_pick(int n, const f
         const uint32_t k = task.node;
         G.k = k;
         s_lo[k] = make_float4(o2f(G.bounds[0]), o2f(G.bounds[1]), o2f(G.bounds[2]), __int_as_float((int)m));
+        if (fs.inner) fs.inner[k] = b;
         s_hi[k] = make_float4(o2f(G.bounds[3]), o2f(G.bounds[4]), o2f(G.bounds[5]), 0.0f);
         sah_attach(st, s_child, task.parent, task.side, TOP + (int)k);
     }
@@ -719,11 +734,11 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const flo
 }
 // (a block role of k_sah_tasks below: it needs the level's k_big_count, nothing of its mid and small tasks)
 __device__ __forceinline__ void sah_big_push_thread(uint32_t t, const SahTask* tasks, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
-                                                    SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, uint32_t level) {
+                                                    SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, uint32_t level, const SahFirst& fs) {
     if (t >= st->cnt[level % 3u][16]) return;
     uint32_t nlft = 0;
     for (uint32_t c = coff[t]; c < coff[t + 1u]; ++c) nlft += chunk_left[c];
-    sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1]);
+    sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1], fs);
 }
 
 // ... and for a SMALL task (<= MPT_SAH_SMALL items: the last three or four levels, which hold most of the tree's nodes and took
@@ -733,7 +748,7 @@ __device__ __forceinline__ void sah_big_push_thread(uint32_t t, const SahTask* t
 // k_sah_level (16 bins over the box centres, cost = area * primitives, ties to the lowest (axis, split)); a lane prices the
 // three planes behind its own item's bins, which are all the planes that separate anything.
 __device__ __forceinline__ void sah_small_thread(uint32_t thread /* among the level's small-task threads */, int n, const float4* in_lo, const float4* in_hi,
-                                                 const SahTask* tasks, SahState* st, int2* s_child, float4* s_lo, float4* s_hi, uint32_t level) {
+                                                 const SahTask* tasks, SahState* st, int2* s_child, float4* s_lo, float4* s_hi, uint32_t level, const SahFirst& fs) {
     const uint32_t n_tasks = st->cnt[level % 3u][32];   // (the grid is sized from an upper bound)
     constexpr uint32_t G = MPT_SAH_SMALL;
     static_assert(G == 8u || G == 16u, "MPT_SAH_SMALL: 8 or 16");
@@ -773,6 +788,7 @@ __device__ __forceinline__ void sah_small_thread(uint32_t thread /* among the le
         const uint32_t k = nb;
         if (live && gl == rb) {
             s_lo[k] = make_float4(nl[0], nl[1], nl[2], __int_as_float((int)m));
+            if (fs.inner) fs.inner[k] = task.b + rb;
             s_hi[k] = make_float4(nh[0], nh[1], nh[2], 0.0f);
             sah_attach(st, s_child, parent, side, TOP + (int)k);
         }
@@ -874,6 +890,7 @@ __device__ __forceinline__ void sah_small_thread(uint32_t thread /* among the le
             if (re - rb == 1u) {   // alone: attached at once
                 if (side == 0u) s_child[k].x = __float_as_int(l.w);
                 else s_child[k].y = __float_as_int(l.w);
+                if (fs.item) fs.item[__float_as_int(l.w)] = task.b + rb;   // (= task.b + gl: the lane holds the item of its own position)
                 live = false;
             }
         }
@@ -887,35 +904,36 @@ __device__ __forceinline__ void sah_small_thread(uint32_t thread /* among the le
 __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_tasks(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
                                                                   const SahTask* small_tasks, const SahTask* big_tasks, SahTask* next, SahTask* next_big,
                                                                   SahTask* next_small, SahState* st, int2* s_child, float4* s_lo, float4* s_hi, const uint32_t* coff,
-                                                                  const SahBig* big, const uint32_t* chunk_left, uint32_t mid_blocks, uint32_t small_blocks, SahLevel lv) {
+                                                                  const SahBig* big, const uint32_t* chunk_left, uint32_t mid_blocks, uint32_t small_blocks, SahLevel lv, SahFirst fs) {
     sah_level_prologue(st, lv);
     if (blockIdx.x < mid_blocks)
-        sah_mid_block(blockIdx.x, n, in_lo, in_hi, out_lo, out_hi, tasks, next, next_big, next_small, st, s_child, s_lo, s_hi, lv.level);
+        sah_mid_block(blockIdx.x, n, in_lo, in_hi, out_lo, out_hi, tasks, next, next_big, next_small, st, s_child, s_lo, s_hi, lv.level, fs);
     else if (blockIdx.x < mid_blocks + small_blocks)
-        sah_small_thread((blockIdx.x - mid_blocks) * (64u * MPT_SAH_WAVES) + threadIdx.x, n, in_lo, in_hi, small_tasks, st, s_child, s_lo, s_hi, lv.level);
+        sah_small_thread((blockIdx.x - mid_blocks) * (64u * MPT_SAH_WAVES) + threadIdx.x, n, in_lo, in_hi, small_tasks, st, s_child, s_lo, s_hi, lv.level, fs);
     else
         sah_big_push_thread((blockIdx.x - mid_blocks - small_blocks) * (64u * MPT_SAH_WAVES) + threadIdx.x, big_tasks, coff, big, chunk_left, next, next_big, next_small, st,
-                            s_child, lv.level);
+                            s_child, lv.level, fs);
 }
 
 // ... and the mid and the small tasks on their own, for the levels that have no big task any more (most of the tree's nodes are made there:
 // in one kernel the two kinds of blocks ran 20 % slower than one after the other, 1060 against 885 us for the last ten levels of 1 M items)
 __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_level(int n, const float4* in_lo, const float4* in_hi, float4* out_lo, float4* out_hi, const SahTask* tasks,
                                                                   SahTask* next, SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, float4* s_lo,
-                                                                  float4* s_hi, SahLevel lv) {
+                                                                  float4* s_hi, SahLevel lv, SahFirst fs) {
     sah_level_prologue(st, lv);
-    sah_mid_block(blockIdx.x, n, in_lo, in_hi, out_lo, out_hi, tasks, next, next_big, next_small, st, s_child, s_lo, s_hi, lv.level);
+    sah_mid_block(blockIdx.x, n, in_lo, in_hi, out_lo, out_hi, tasks, next, next_big, next_small, st, s_child, s_lo, s_hi, lv.level, fs);
 }
 __global__ __launch_bounds__(256) void k_sah_small(int n, const float4* in_lo, const float4* in_hi, const SahTask* tasks, SahState* st, int2* s_child, float4* s_lo,
-                                                   float4* s_hi, SahLevel lv) {
+                                                   float4* s_hi, SahLevel lv, SahFirst fs) {
     sah_level_prologue(st, lv);
-    sah_small_thread(blockIdx.x * blockDim.x + threadIdx.x, n, in_lo, in_hi, tasks, st, s_child, s_lo, s_hi, lv.level);
+    sah_small_thread(blockIdx.x * blockDim.x + threadIdx.x, n, in_lo, in_hi, tasks, st, s_child, s_lo, s_hi, lv.level, fs);
 }
 
 struct SahTree {
     int2* child = nullptr;
     float4 *lo = nullptr, *hi = nullptr;
     SahState* st = nullptr;   // on the device: root, n_nodes
+    SahFirst first = {nullptr, nullptr};   // (in: arrays the caller wants filled — SahFirst above)
 };
 // it_lo / it_hi: the items (device, consumed: the partitions ping-pong between them and two scratch arrays).  The item count
 // is *d_count if d_count is not null (a device word), else count_host; max_items bounds it.  pin: >= 1 KiB of pinned host memory.
@@ -1005,7 +1023,7 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
             hipLaunchKernelGGL(k_big_bounds, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
                                (const SahState*)T.st, (const uint32_t*)coff, bigs, lvl);
             hipLaunchKernelGGL(k_big_pick, dim3(b_big), dim3(MPT_SAH_BIG_THREADS), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a, bigs,
-                               T.st, T.child, T.lo, T.hi, lvl);
+                               T.st, T.child, T.lo, T.hi, lvl, T.first);
             hipLaunchKernelGGL(k_big_count, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, (const SahTask*)big_a,
                                (const SahState*)T.st, (const uint32_t*)coff, (const SahBig*)bigs, chunk_left, lvl);
             hipLaunchKernelGGL(k_big_scatter, dim3(chunks), dim3(MPT_SAH_CHUNK_THREADS), 0, stream, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b, it_hi_b,
@@ -1016,14 +1034,14 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
                            push_blocks = (b_big + TH - 1) / TH;
             hipLaunchKernelGGL(k_sah_tasks, dim3(mid_blocks + small_blocks + push_blocks), dim3(TH), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b,
                                it_hi_b, (const SahTask*)tasks_a, (const SahTask*)small_a, (const SahTask*)big_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi,
-                               (const uint32_t*)coff, (const SahBig*)bigs, (const uint32_t*)chunk_left, mid_blocks, small_blocks, take());
+                               (const uint32_t*)coff, (const SahBig*)bigs, (const uint32_t*)chunk_left, mid_blocks, small_blocks, take(), T.first);
         } else {
             if (b_mid)
                 hipLaunchKernelGGL(k_sah_level, dim3((b_mid + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES), dim3(64 * MPT_SAH_WAVES), 0, stream, n, (const float4*)it_lo_a,
-                                   (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi, take());
+                                   (const float4*)it_hi_a, it_lo_b, it_hi_b, (const SahTask*)tasks_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi, take(), T.first);
             if (b_small || first.stamp != 0u)   // (a level with no grid at all still publishes its counts: zeroes, which end the loop)
                 hipLaunchKernelGGL(k_sah_small, dim3((uint32_t)(((size_t)std::max(b_small, 1u) * MPT_SAH_SMALL + 255) / 256)), dim3(256), 0, stream, n, (const float4*)it_lo_a,
-                                   (const float4*)it_hi_a, (const SahTask*)small_a, T.st, T.child, T.lo, T.hi, take());
+                                   (const float4*)it_hi_a, (const SahTask*)small_a, T.st, T.child, T.lo, T.hi, take(), T.first);
         }
         MPT_LB(hipGetLastError());
         // bounds of level + 1 from the newest exact counts: those of level - 1 at the latest (the device is past them or about to
