@@ -406,6 +406,7 @@ __device__ __forceinline__ int4 collapse_pick(const CollapseAcc& A, int b, uint3
                     }
                 if (bi < 0) break;
                 const int2 g = A.child(ch[bi]);
+                if (g.x < 0 || g.y < 0) break;   // (a node nobody made: cannot be reached from the root either — k_collapse_picks prices every node)
                 ch[bi] = g.x;
                 ch[nc++] = g.y;
             }
@@ -416,39 +417,36 @@ __device__ __forceinline__ int4 collapse_pick(const CollapseAcc& A, int b, uint3
     *nint_out = nint;
     return make_int4(ch[0], ch[1], ch[2], ch[3]);
 }
+// Round 5: the picks of ALL inner nodes of the binary tree at once, before the level loop.  A pick is a chain of five dependent loads (the
+// children, their boxes, the opened child's children, their boxes, ...); made by the thread that emits the parent, as in the first half of
+// the round, that chain was the duration of every level (17-24 us each, thirteen levels); here half a million of them overlap.  Only about
+// half of the nodes become wide nodes, the others' picks are never read.
+// dense: the tree is run_sah's (inner nodes 0 .. n_nodes - 1, all made); else the refitted one, whose unmade nodes hold child -1.
+__global__ void k_collapse_picks(CollapseAcc A, uint32_t n_bound, const SahState* st, int dense, int4* picks, uint32_t* pn) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_bound) return;
+    if (dense ? k >= st->n_nodes : A.s_child[k].x < 0 || A.s_child[k].y < 0) return;
+    picks[k] = collapse_pick(A, A.TOP + (int)k, pn + k);
+}
 // No host wait inside the level loop (round 5; until round 4 the host read the size of the next level back after every level: 12 idle gaps
-// of ~20 us for 1 M primitives, and three more launches a level).  The levels' bounds live on the device (lev[L] = first node, end), the
-// grids are sized from an upper bound (a level has at most four times the nodes of the one before), and a node's children are PICKED by the
-// thread that emits their parent, so a level is one scan and one kernel.  The size of the next level goes to a slot of pinned host memory
-// with a stamp; the host reads it a level late, to end the loop (mpt_sah.h run_sah does the same).
+// of ~20 us for 1 M primitives, and three more launches a level).  The levels' bounds live on the device (lev[i] = first node, end), the
+// grids are sized from an upper bound (a level has at most four times the nodes of the one before), a level is one scan and one kernel.  The
+// size of the next level goes to a slot of pinned host memory with a stamp; the host reads it a level late, to end the loop (mpt_sah.h
+// run_sah does the same).  The first levels — while a level has at most 1024 nodes — are made by ONE workgroup in one launch
+// (k_collapse_top: six levels of a 1 M-primitive tree), which leaves the first larger level's nodes for the loop.
 struct CollapseLevel {
     uint32_t begin, end;
 };
-__global__ void k_collapse_root(CollapseAcc A, const SahState* st, int4* picked, uint32_t* nint, CollapseLevel* lev) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    picked[0] = collapse_pick(A, st->root, nint);
-    lev[0] = CollapseLevel{0u, 1u};
-}
-__global__ void k_collapse_level(CollapseAcc A, int n, const int2* range, const uint32_t* pfirst, CollapseLevel* lev, uint32_t L, const int4* picked, const uint32_t* offs,
-                                 int4* picked_next, uint32_t* nint_next, float4* acc_nodes, uint32_t cap, Scalars* sc, unsigned long long* host_slot, uint32_t stamp) {
-    const uint32_t begin = lev[L].begin, end = lev[L].end, cnt = end - begin;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) {
-        const uint32_t total = cnt ? offs[cnt] : 0u;   // inner children of the level = the nodes of the next one
-        lev[L + 1u] = CollapseLevel{end, end + total};
-        if (cnt) {
-            sc->n_acc_nodes = end;
-            sc->acc_depth = L + 1u;
-        }
-        // (ONE 8-byte store: no system-scope fence — a write-back of the L2 — beside the level's other workgroups; mpt_sah.h sah_level_prologue)
-        __hip_atomic_store(host_slot, (unsigned long long)stamp << 32 | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    const uint32_t k = begin + t;
-    if (t >= cnt || k >= cap) return;
-    const float pad = fmaxf(__uint_as_float(sc->tri_extent), 1e-6f) * 6.103515625e-05f;  // 2^-14: covers the rcp / fma slab arithmetic
-    const int4 p = picked[t];
+struct CollapseHead {
+    uint32_t depth_base;   // levels made by k_collapse_top
+    uint32_t pad[3];
+    CollapseLevel lev[132];   // lev[i]: the nodes of the loop's i-th level
+};
+// writes wide node k, whose children are p; its inner children are nodes at, at + 1, ...: their binary nodes go to w_next[0 ..], the number
+// of inner children of each to n_next[0 ..] (both already offset to this node's first child)
+__device__ __forceinline__ void collapse_emit(const CollapseAcc& A, int n, const int2* range, const uint32_t* pfirst, const uint32_t* pn, int4 p, uint32_t k, uint32_t at,
+                                              uint32_t cap, float pad, float4* acc_nodes, int* w_next, uint32_t* n_next) {
     const int ch[4] = {p.x, p.y, p.z, p.w};
-    const uint32_t first = offs[t], at = end + first;
     float o[4 * MPT_OT_NODE_STRIDE];
     for (uint32_t q = 0; q < 4u * MPT_OT_NODE_STRIDE; ++q) o[q] = 0.0f;
     uint32_t j = 0;
@@ -463,7 +461,10 @@ __global__ void k_collapse_level(CollapseAcc A, int n, const int2* range, const 
                 ref = MPT_ACCEL_LEAF | ((uint32_t)(span_of(range, n, ch[c]) - 1) << 27) | pfirst[ch[c]];
             } else {
                 ref = at + j;
-                if (at + j < cap) picked_next[first + j] = collapse_pick(A, ch[c], nint_next + first + j);
+                if (at + j < cap) {
+                    w_next[j] = ch[c];
+                    if (n_next) n_next[j] = pn[ch[c] - A.TOP];
+                }
                 ++j;
             }
         }
@@ -475,6 +476,86 @@ __global__ void k_collapse_level(CollapseAcc A, int n, const int2* range, const 
     }
     float4* dst = acc_nodes + (size_t)k * MPT_OT_NODE_STRIDE;
     for (uint32_t q = 0; q < MPT_OT_NODE_STRIDE; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+#define MPT_COLLAPSE_TOP 1024u   // k_collapse_top makes the levels of at most this many nodes
+__global__ __launch_bounds__(MPT_COLLAPSE_TOP) void k_collapse_top(CollapseAcc A, int n, const int2* range, const uint32_t* pfirst, const SahState* st, const int4* picks,
+                                                                   const uint32_t* pn, CollapseHead* head, int* w_out, uint32_t* n_out, float4* acc_nodes, uint32_t cap,
+                                                                   Scalars* sc) {
+    __shared__ int s_w[2][4u * MPT_COLLAPSE_TOP];   // the binary nodes of the level, and of the next one (at most four times as many)
+    __shared__ uint32_t s_wave[MPT_COLLAPSE_TOP / 64u];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const float pad = fmaxf(__uint_as_float(sc->tri_extent), 1e-6f) * 6.103515625e-05f;  // 2^-14: covers the rcp / fma slab arithmetic
+    if (tid == 0) s_w[0][0] = st->root;
+    uint32_t begin = 0, end = 1, cur = 0, depth = 0;
+    __syncthreads();
+    while (end - begin != 0u && end - begin <= MPT_COLLAPSE_TOP) {
+        const uint32_t cnt = end - begin;
+        int4 p = make_int4(-1, -1, -1, -1);
+        uint32_t nint = 0;
+        if (tid < cnt) {
+            const int wb = s_w[cur][tid];
+            if (wb >= A.TOP) {
+                p = picks[wb - A.TOP];
+                nint = pn[wb - A.TOP];
+            } else {
+                p.x = wb;   // (the root is a leaf, or there is no tree: -1)
+            }
+        }
+        // exclusive scan of nint over the workgroup
+        uint32_t x = nint;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if ((int)lane >= off) x += y;
+        }
+        if (lane == 63u) s_wave[wv] = x;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < MPT_COLLAPSE_TOP / 64u; ++w) {
+            if (w < wv) before += s_wave[w];
+            total += s_wave[w];
+        }
+        const uint32_t first = before + x - nint;
+        if (tid < cnt && begin + tid < cap) collapse_emit(A, n, range, pfirst, pn, p, begin + tid, end + first, cap, pad, acc_nodes, &s_w[cur ^ 1u][first], nullptr);
+        __syncthreads();
+        ++depth;
+        begin = end;
+        end += total;
+        cur ^= 1u;
+    }
+    // what is left is the loop's: its first level's nodes, their counts of inner children
+    const uint32_t cnt = end - begin;
+    for (uint32_t i = tid; i < cnt && begin + i < cap; i += MPT_COLLAPSE_TOP) {
+        const int wb = s_w[cur][i];
+        w_out[i] = wb;
+        n_out[i] = pn[wb - A.TOP];
+    }
+    if (tid == 0) {
+        head->depth_base = depth;
+        head->lev[0] = CollapseLevel{begin, end};
+        sc->n_acc_nodes = begin;
+        sc->acc_depth = depth;
+    }
+}
+__global__ void k_collapse_level(CollapseAcc A, int n, const int2* range, const uint32_t* pfirst, CollapseHead* head, uint32_t L, const int4* picks, const uint32_t* pn,
+                                 const int* wbin, const uint32_t* offs, int* w_next, uint32_t* n_next, float4* acc_nodes, uint32_t cap, Scalars* sc,
+                                 unsigned long long* host_slot, uint32_t stamp) {
+    const uint32_t begin = head->lev[L].begin, end = head->lev[L].end, cnt = end - begin;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        const uint32_t total = cnt ? offs[cnt] : 0u;   // inner children of the level = the nodes of the next one
+        head->lev[L + 1u] = CollapseLevel{end, end + total};
+        if (cnt) {
+            sc->n_acc_nodes = end;
+            sc->acc_depth = head->depth_base + L + 1u;
+        }
+        // (ONE 8-byte store: no system-scope fence — a write-back of the L2 — beside the level's other workgroups; mpt_sah.h sah_level_prologue)
+        __hip_atomic_store(host_slot, (unsigned long long)stamp << 32 | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const uint32_t k = begin + t;
+    if (t >= cnt || k >= cap) return;
+    const float pad = fmaxf(__uint_as_float(sc->tri_extent), 1e-6f) * 6.103515625e-05f;  // 2^-14: covers the rcp / fma slab arithmetic
+    const uint32_t first = offs[t];
+    collapse_emit(A, n, range, pfirst, pn, picks[wbin[t] - A.TOP], k, end + first, cap, pad, acc_nodes, w_next + first, n_next + first);
 }
 
 // refbox[2 i], [2 i + 1] = the box of primitive i's reference leaf, what ot_final_check (mpt_ordered.h) tests the winner against:
@@ -735,6 +816,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         MPT_LB(sc.alloc(&s_hi, n));
         MPT_LB(hipMemsetAsync(arrived, 0, nn * 4, stream));
         MPT_LB(hipMemsetAsync(d_st, 0xFF, sizeof(SahState), stream));   // root = -1
+        MPT_LB(hipMemsetAsync(s_child, 0xFF, (size_t)n * sizeof(int2), stream));   // (children -1: a node nobody made — k_collapse_picks)
         // (the copy is valid when every leaf's own box is its reference box or, in the chain of hoisted items, empty: spheres hoisted or none
         //  — with spheres INSIDE the SAH's leaves and no always list the boxes agree too, but then nothing marks the chain: the walk)
         const bool fast = (R.spheres_hoisted || n_spheres_hint == 0) && getenv("MPT_OWN_TREE_WALK") == nullptr;
@@ -772,15 +854,18 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     }
     const uint32_t cap = std::min(max_items, n) + 2u;   // wide nodes <= inner nodes of the SAH tree over the leaves (+ the root of a one-leaf tree)
     {
-        uint32_t *nint_a, *nint_b, *c_offs;
-        int4 *picked_a, *picked_b;
-        CollapseLevel* lev;
+        uint32_t *nint_a, *nint_b, *c_offs, *pn;
+        int *wbin_a, *wbin_b;
+        int4* picks;
+        CollapseHead* head;
         MPT_LB(sc.alloc(&nint_a, cap + 1));
         MPT_LB(sc.alloc(&nint_b, cap + 1));
         MPT_LB(sc.alloc(&c_offs, cap + 1));
-        MPT_LB(sc.alloc(&picked_a, cap));
-        MPT_LB(sc.alloc(&picked_b, cap));
-        MPT_LB(sc.alloc(&lev, 130));
+        MPT_LB(sc.alloc(&wbin_a, cap));
+        MPT_LB(sc.alloc(&wbin_b, cap));
+        MPT_LB(sc.alloc(&picks, n));
+        MPT_LB(sc.alloc(&pn, n));
+        MPT_LB(sc.alloc(&head, 1));
         const CollapseAcc A = {s_child, s_lo, s_hi, olo, ohi, (int)(2 * n - 1)};
         size_t sb = 0;
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, nint_a, c_offs, (int)cap + 1, stream));
@@ -792,14 +877,16 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         unsigned long long* d_slots = nullptr;
         MPT_LB(hipHostGetDevicePointer((void**)&d_slots, pin + 128, 0));
         for (int q = 0; q < 8; ++q) slots[q] = 0ull;
-        hipLaunchKernelGGL(k_collapse_root, dim3(1), dim3(64), 0, stream, A, (const SahState*)d_st, picked_a, nint_a, lev);
-        uint32_t bound = 1;   // upper bound of the level about to be enqueued
+        hipLaunchKernelGGL(k_collapse_picks, dim3((n + B - 1) / B), dim3(B), 0, stream, A, n, (const SahState*)d_st, refit ? 0 : 1, picks, pn);
+        hipLaunchKernelGGL(k_collapse_top, dim3(1), dim3(MPT_COLLAPSE_TOP), 0, stream, A, (int)n, (const int2*)R.range, (const uint32_t*)pfirst, (const SahState*)d_st,
+                           (const int4*)picks, (const uint32_t*)pn, head, wbin_a, nint_a, out.acc_nodes, cap, d_sc);
+        uint32_t bound = std::min(4u * MPT_COLLAPSE_TOP, cap);   // upper bound of the level about to be enqueued (the first: what k_collapse_top leaves)
         bool done = false;
         for (uint32_t L = 0; L < 128u && !done; ++L) {
             MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp, sb, nint_a, c_offs, (int)bound + 1, stream));
-            hipLaunchKernelGGL(k_collapse_level, dim3((bound + B - 1) / B), dim3(B), 0, stream, A, (int)n, (const int2*)R.range, (const uint32_t*)pfirst, lev, L,
-                               (const int4*)picked_a, (const uint32_t*)c_offs, picked_b, nint_b, out.acc_nodes, cap, d_sc, d_slots + (L & 7u),
-                               epoch | (L + 1u));
+            hipLaunchKernelGGL(k_collapse_level, dim3((bound + B - 1) / B), dim3(B), 0, stream, A, (int)n, (const int2*)R.range, (const uint32_t*)pfirst, head, L,
+                               (const int4*)picks, (const uint32_t*)pn, (const int*)wbin_a, (const uint32_t*)c_offs, wbin_b, nint_b, out.acc_nodes, cap, d_sc,
+                               d_slots + (L & 7u), epoch | (L + 1u));
             MPT_LB(hipGetLastError());
             uint32_t next_bound = (uint32_t)std::min<uint64_t>(4ull * bound, cap);
             if (L >= 1u) {   // the size of level L (slot L - 1), which the device is at or past: nothing there = the tree is complete
@@ -819,7 +906,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
             }
             bound = std::max(next_bound, 1u);
             std::swap(nint_a, nint_b);
-            std::swap(picked_a, picked_b);
+            std::swap(wbin_a, wbin_b);
         }
         if (!done) return hipErrorUnknown;
     }

@@ -216,7 +216,9 @@ __device__ __forceinline__ void sah_level_prologue(SahState* st, const SahLevel&
     __hip_atomic_store(lv.host_slot + 1, stamp << 32 | b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(lv.host_slot + 2, stamp << 32 | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+#ifndef MPT_SAH_WAVES
 #define MPT_SAH_WAVES 16   // tasks (waves) per workgroup
+#endif
 // Where a node's items start in the final item order (the order the partitions leave: left sub-tree first) — known the moment the node is
 // made, or an item is left alone: inner[k] for inner node k, item[id] for an item.  Either may be null.  (mpt_lbvh.h numbers the nodes of
 // the reference-format tree by these; until round 5 a kernel of its own walked from every node to the root to find them, 105 us for 1 M.)
@@ -272,18 +274,34 @@ __device__ __forceinline__ void sah_mid_block(uint32_t block, int n, const float
     float nl[3] = {INFINITY, INFINITY, INFINITY}, nh[3] = {-INFINITY, -INFINITY, -INFINITY}, cl[3] = {INFINITY, INFINITY, INFINITY},
           ch[3] = {-INFINITY, -INFINITY, -INFINITY};
     unsigned long long largest = 0ull;   // (bits of the area) << 32 | item: the item with the largest box (see the sample below)
-    for (uint32_t i = b + lane; i < e; i += 64u) {
-        const float4 l = in_lo[i], h = in_hi[i];
-        const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
-        for (int a = 0; a < 3; ++a) {
-            nl[a] = fminf(nl[a], lo3[a]);
-            nh[a] = fmaxf(nh[a], hi3[a]);
-            const float c = 0.5f * (lo3[a] + hi3[a]);
-            cl[a] = fminf(cl[a], c);
-            ch[a] = fmaxf(ch[a], c);
+    // (four items a lane per trip, all eight loads in flight before the first is used: a task of 2000 items is 32 dependent round trips
+    //  otherwise, and the levels whose few hundred tasks are all of that size took 62-68 us each with the chip nearly idle)
+    for (uint32_t i0 = b + lane; i0 < e; i0 += 256u) {
+        float4 l4[4], h4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            if (i < e) {
+                l4[u] = in_lo[i];
+                h4[u] = in_hi[i];
+            }
         }
-        const unsigned long long key = sah_area_key(l, h, i);
-        largest = key > largest ? key : largest;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            if (i >= e) break;
+            const float4 l = l4[u], h = h4[u];
+            const float lo3[3] = {l.x, l.y, l.z}, hi3[3] = {h.x, h.y, h.z};
+            for (int a = 0; a < 3; ++a) {
+                nl[a] = fminf(nl[a], lo3[a]);
+                nh[a] = fmaxf(nh[a], hi3[a]);
+                const float c = 0.5f * (lo3[a] + hi3[a]);
+                cl[a] = fminf(cl[a], c);
+                ch[a] = fmaxf(ch[a], c);
+            }
+            const unsigned long long key = sah_area_key(l, h, i);
+            largest = key > largest ? key : largest;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(largest, off);
@@ -368,14 +386,21 @@ __device__ __forceinline__ void sah_mid_block(uint32_t block, int n, const float
     // partition into the other array: left from b upwards, right from e - 1 downwards
     uint32_t nlft = 0, nrgt = 0;
     int one_left = 0, one_right = 0;   // (the first item that went to either side: THE item if it stays alone)
+    float4 l_next = make_float4(0, 0, 0, 0), h_next = l_next;   // (the next trip's items are on their way while this trip's are placed)
+    if (b + lane < e) {
+        l_next = in_lo[b + lane];
+        h_next = in_hi[b + lane];
+    }
     for (uint32_t base = b; base < e; base += 64u) {
         const uint32_t i = base + lane;
         const bool valid = i < e;
-        float4 l = make_float4(0, 0, 0, 0), h = l;
+        float4 l = l_next, h = h_next;
+        if (i + 64u < e) {
+            l_next = in_lo[i + 64u];
+            h_next = in_hi[i + 64u];
+        }
         bool left = false;
         if (valid) {
-            l = in_lo[i];
-            h = in_hi[i];
             if (pick >= 0) {
                 int q = (int)((0.5f * (axis_of(l, paxis) + axis_of(h, paxis)) - cl[paxis]) * inv[paxis]);
                 q = q < 0 ? 0 : (q > 15 ? 15 : q);
