@@ -626,6 +626,21 @@ static size_t out_block_bytes(uint32_t n) {
 static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint, Built& out,
                              mpt_lbvh::ScratchPool* pool, void** spare, size_t* spare_bytes, bool wide_mat_sort, bool* mat_collision) {
     Scratch sc(pool);
+    // Two streams (round 5): the material chain (hash, sort, table: ~0.19 ms of small kernels for 1 M primitives) needs nothing of the tree until
+    // the leaves are written, and the threaded tree (depths, their sort, the emission: ~0.13 ms) nothing of the own tree's collapse — each runs
+    // on the pool's side stream beside the main one, forked and joined by events.  Without a pool: everything on `stream`, as before.
+    hipStream_t side = stream;
+    if (pool && getenv("MPT_BUILD_ONE_STREAM") == nullptr) MPT_LB(pool->side_stream(&side));
+    const bool two = side != stream;
+    struct SideGuard {   // (no scratch chunk goes back to the pool while the side stream may still use it: declared after `sc`, run before it)
+        hipStream_t s;
+        ~SideGuard() { if (s) hipStreamSynchronize(s); }
+    } side_guard{two ? side : nullptr};
+    auto hand_over = [&](hipStream_t from, hipStream_t to, int e) -> hipError_t {   // what `to` does next comes after what `from` has been given so far
+        if (!two) return hipSuccess;
+        MPT_LB(hipEventRecord(pool->ev[e], from));
+        return hipStreamWaitEvent(to, pool->ev[e], 0);
+    };
     {
         const size_t need = out_block_bytes(n);
         if (spare && *spare && *spare_bytes >= need) {
@@ -662,6 +677,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     uint32_t* pin = pinned.p;
     MPT_LB(sc.alloc(&d_sc, 1));
     MPT_LB(hipMemsetAsync(d_sc, 0, sizeof(Scalars), stream));
+    MPT_LB(hand_over(stream, side, 0));   // (the caller's uploads and the zeroed scalars)
     const uint32_t B = 256, gn = (n + B - 1) / B;
     hipLaunchKernelGGL(k_tri_extent, dim3(std::min(gn, 1024u)), dim3(B), 0, stream, (const float4*)d_prims_in, n, d_sc);
     // materials
@@ -695,30 +711,30 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     }
     uint32_t key_mask = 0xFFFFFFFFu;
     if (const char* e = getenv("MPT_DEBUG_MAT_KEY_MASK")) key_mask = (uint32_t)strtoul(e, nullptr, 16);
-    hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, stream, d_mats_in, n, mk, mk32, key_mask, mi);
+    hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, side, d_mats_in, n, mk, mk32, key_mask, mi);
     {
         const uint32_t *ids_sorted = mi2, *keys32_sorted = nullptr;
         if (wide_mat_sort) {
             size_t bytes = 0;
-            MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, stream));
+            MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, side));
             char* tmp;
             MPT_LB(sc.alloc(&tmp, bytes));
-            MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, stream));
+            MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, side));
         } else {
             mpt_radix::RadixTemp RT;
-            MPT_LB(mpt_radix::radix_reserve(sc, n, stream, RT));
+            MPT_LB(mpt_radix::radix_reserve(sc, n, side, RT));
             bool second = false;
-            MPT_LB(mpt_radix::radix_sort_pairs(stream, RT, mk32, mi, mk32s, mi2, n, 4, &second));
+            MPT_LB(mpt_radix::radix_sort_pairs(side, RT, mk32, mi, mk32s, mi2, n, 4, &second));
             ids_sorted = second ? mi2 : mi;
             keys32_sorted = second ? mk32s : mk32;
         }
-        hipLaunchKernelGGL(k_mat_heads, dim3(gn), dim3(B), 0, stream, d_mats_in, ids_sorted, keys32_sorted, n, mhead, d_sc);
+        hipLaunchKernelGGL(k_mat_heads, dim3(gn), dim3(B), 0, side, d_mats_in, ids_sorted, keys32_sorted, n, mhead, d_sc);
         size_t sb = 0;
-        MPT_LB(hipcub::DeviceScan::InclusiveSum(nullptr, sb, mhead, mrank, (int)n, stream));
+        MPT_LB(hipcub::DeviceScan::InclusiveSum(nullptr, sb, mhead, mrank, (int)n, side));
         char* tmp2;
         MPT_LB(sc.alloc(&tmp2, sb));
-        MPT_LB(hipcub::DeviceScan::InclusiveSum(tmp2, sb, mhead, mrank, (int)n, stream));
-        hipLaunchKernelGGL(k_mat_scatter, dim3(gn), dim3(B), 0, stream, d_mats_in, ids_sorted, (const uint32_t*)mhead, (const uint32_t*)mrank, n,
+        MPT_LB(hipcub::DeviceScan::InclusiveSum(tmp2, sb, mhead, mrank, (int)n, side));
+        hipLaunchKernelGGL(k_mat_scatter, dim3(gn), dim3(B), 0, side, d_mats_in, ids_sorted, (const uint32_t*)mhead, (const uint32_t*)mrank, n,
                            mat_of_prim, mtable, d_sc);
     }
     // the binary tree
@@ -773,10 +789,12 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, sb, cnt, pos, (int)nl, stream));
         hipLaunchKernelGGL(k_pfirst_scatter, dim3(gl), dim3(B), 0, stream, nl, (const uint32_t*)node_s, (const uint32_t*)pos, pfirst);
     }
+    MPT_LB(hand_over(side, stream, 1));   // (mat_of_prim)
     hipLaunchKernelGGL(k_leaves, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int2*)R.range, (const uint32_t*)is_leaf, (const uint32_t*)leaf_id,
                        (const uint32_t*)R.vals, (const float4*)d_prims_in, (const uint32_t*)mat_of_prim, (const float4*)R.nlo, (const float4*)R.nhi,
                        (const uint32_t*)pfirst, out.prims, out.refleaf, olo, ohi, d_sc, use_always);
-    // threaded tree, breadth-first
+    // threaded tree, breadth-first — and the per-primitive leaf boxes: on the side stream, beside the own tree
+    MPT_LB(hand_over(stream, side, 2));   // (the leaves)
     uint32_t *depth_c, *depth_s, *id_c, *order, *tpos;
     int* skip;
     MPT_LB(sc.alloc(&depth_c, n_out));
@@ -785,17 +803,19 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     MPT_LB(sc.alloc(&order, n_out));
     MPT_LB(sc.alloc(&tpos, nn));
     MPT_LB(sc.alloc(&skip, nn));
-    hipLaunchKernelGGL(k_depth_skip, dim3(gnn), dim3(B), 0, stream, (int)n, (const uint32_t*)R.keep, (const uint32_t*)R.index, (const int2*)R.child,
+    hipLaunchKernelGGL(k_depth_skip, dim3(gnn), dim3(B), 0, side, (int)n, (const uint32_t*)R.keep, (const uint32_t*)R.index, (const int2*)R.child,
                        (const int*)R.parent, depth_c, id_c, skip);
     {   // (one counting pass over the 8-bit depths, stable: breadth-first, the builder's order within a level)
         mpt_radix::RadixTemp RT;
-        MPT_LB(mpt_radix::radix_reserve(sc, n_out, stream, RT));
+        MPT_LB(mpt_radix::radix_reserve(sc, n_out, side, RT));
         bool second = false;
-        MPT_LB(mpt_radix::radix_sort_pairs(stream, RT, depth_c, id_c, depth_s, order, n_out, 1, &second));
+        MPT_LB(mpt_radix::radix_sort_pairs(side, RT, depth_c, id_c, depth_s, order, n_out, 1, &second));
     }
-    hipLaunchKernelGGL(k_positions, dim3(go), dim3(B), 0, stream, n_out, (const uint32_t*)order, tpos);
-    hipLaunchKernelGGL(k_emit_threaded, dim3(go), dim3(B), 0, stream, n_out, (int)n, (const uint32_t*)order, (const uint32_t*)tpos, (const uint32_t*)is_leaf,
+    hipLaunchKernelGGL(k_positions, dim3(go), dim3(B), 0, side, n_out, (const uint32_t*)order, tpos);
+    hipLaunchKernelGGL(k_emit_threaded, dim3(go), dim3(B), 0, side, n_out, (int)n, (const uint32_t*)order, (const uint32_t*)tpos, (const uint32_t*)is_leaf,
                        (const int2*)R.child, (const int2*)R.range, (const uint32_t*)pfirst, (const int*)skip, (const float4*)R.nlo, (const float4*)R.nhi, out.nodes);
+    hipLaunchKernelGGL(k_prim_refbox, dim3((n + 255u) / 256u), dim3(256), 0, side, (const float4*)out.prims, (const float4*)out.refleaf, n, out.refbox);
+    MPT_LB(hipGetLastError());
     // own tree: its binary tree (the builder's own SAH tree refitted, or a binned SAH over the leaves: mpt_sah.h), then the 4-wide collapse
     const uint32_t max_items = n_out;   // (leaves <= output nodes)
     SahState* d_st;
@@ -912,8 +932,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     }
     hipLaunchKernelGGL(k_always, dim3(1), dim3(64), 0, stream, d_sc, out.prims, (const float4*)out.refleaf, out.always);
     MPT_LB(hipGetLastError());
-    hipLaunchKernelGGL(k_prim_refbox, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const float4*)out.prims, (const float4*)out.refleaf, n, out.refbox);
-    MPT_LB(hipGetLastError());
+    MPT_LB(hand_over(side, stream, 3));
     Scalars& h = *(Scalars*)(pin + 192);   // (pinned: a pageable target costs ~0.3 ms per copy)
     static_assert(sizeof(Scalars) + 4 <= 256, "Scalars must fit the last quarter of the pinned block");
     uint32_t& n_leaves = pin[192 + sizeof(Scalars) / 4];

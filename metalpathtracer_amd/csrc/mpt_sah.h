@@ -22,12 +22,30 @@ struct ScratchPool {
     std::vector<std::pair<void*, size_t>> chunks;
     size_t keep_bytes = (size_t)2 << 30;   // what stays allocated between builds at most
     uint32_t* pin = nullptr;               // 2 KiB of pinned host memory for the builders' read-backs (hipHostMalloc per build: ~0.1 ms each)
+    hipStream_t side = nullptr;            // a second stream for the chains of a build that need nothing of one another (mpt_devbuild.h) ...
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // ... and the events that fork and join it
     ~ScratchPool() { release(); }
     void release() {
         for (auto& c : chunks) hipFree(c.first);
         chunks.clear();
         if (pin) hipHostFree(pin);
         pin = nullptr;
+        if (side) hipStreamDestroy(side);
+        side = nullptr;
+        for (auto& e : ev) {
+            if (e) hipEventDestroy(e);
+            e = nullptr;
+        }
+    }
+    hipError_t side_stream(hipStream_t* out) {
+        if (!side) {
+            hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+            for (auto& v : ev)
+                if ((e = hipEventCreateWithFlags(&v, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        *out = side;
+        return hipSuccess;
     }
 };
 // 1 KiB of pinned host memory for one builder's read-backs: part `which` (0 / 1) of the pool's block, or the builder's own for the call
