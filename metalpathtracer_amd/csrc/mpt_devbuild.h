@@ -43,8 +43,9 @@ __device__ __forceinline__ int span_of(const int2* range, int n, int node) { ret
 __device__ __forceinline__ int first_of(const int2* range, int n, int node) { return node >= n - 1 ? node - (n - 1) : range[node].x; }
 
 // ---- materials: sort by a 64-bit hash, mark the runs, number them ---------------------------------------------------------
-// keys: all 64 bits of the hash; keys32 (if not null): its upper half (& key_mask: the tests force collisions with a narrow one)
-__global__ void k_mat_hash(const float4* mats, uint32_t n, unsigned long long* keys, uint32_t* keys32, uint32_t key_mask, uint32_t* ids) {
+// keys: all 64 bits of the hash; keys32 (if not null): its upper half (>> key_shift: the tests force collisions by keeping a few bits only —
+// the TOP ones, so that without a collision the order is still that of the whole hash)
+__global__ void k_mat_hash(const float4* mats, uint32_t n, unsigned long long* keys, uint32_t* keys32, uint32_t key_shift, uint32_t* ids) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4 a = ((const uint4*)mats)[2 * (size_t)i], b = ((const uint4*)mats)[2 * (size_t)i + 1];
@@ -55,7 +56,7 @@ __global__ void k_mat_hash(const float4* mats, uint32_t n, unsigned long long* k
         h *= 0x100000001b3ull;
         h ^= h >> 29;
     }
-    if (keys32) keys32[i] = (uint32_t)(h >> 32) & key_mask;
+    if (keys32) keys32[i] = (uint32_t)(h >> 32) >> key_shift;
     else keys[i] = h;
     ids[i] = i;
 }
@@ -709,9 +710,9 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         MPT_LB(sc.alloc(&mk32, n));
         MPT_LB(sc.alloc(&mk32s, n));
     }
-    uint32_t key_mask = 0xFFFFFFFFu;
-    if (const char* e = getenv("MPT_DEBUG_MAT_KEY_MASK")) key_mask = (uint32_t)strtoul(e, nullptr, 16);
-    hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, side, d_mats_in, n, mk, mk32, key_mask, mi);
+    uint32_t key_shift = 0u;
+    if (const char* e = getenv("MPT_DEBUG_MAT_KEY_BITS")) key_shift = 32u - (uint32_t)std::min(std::max(atoi(e), 1), 32);
+    hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, side, d_mats_in, n, mk, mk32, key_shift, mi);
     {
         const uint32_t *ids_sorted = mi2, *keys32_sorted = nullptr;
         if (wide_mat_sort) {

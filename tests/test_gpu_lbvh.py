@@ -108,6 +108,42 @@ def test_gpu_build_small_inputs_and_determinism(gpu_ctx, builder, monkeypatch):
         assert (n <= capi_leaf(n)) == (bvh.shape[0] == 1)            # a scene that fits one leaf (mpt_gpu_leaf_max) is one node
 
 
+def _digest(ctx):
+    return ["%016x" % v for v in ctx.scene_digest()]
+
+
+@pytest.mark.parametrize("builder", ["sah", "ploc", "lbvh"])
+@pytest.mark.parametrize("name", ["scene.xml", "cornell.xml", "glass.xml", "bunny20.xml"])
+def test_device_build_writes_the_recorded_arrays(gpu_ctx, name, builder, monkeypatch):
+    """Every device array mpt_build_and_upload makes — threaded tree, primitive records, materials, own 4-wide tree, leaf boxes, always
+    list, the reference-format tree — has the digest (mpt_scene_digest) recorded in tests/golden/devbuild_digests.json by the build of
+    round 5's first half (tools/gpu_scene_digest.py --write, commit 192df6b): the builder's later rewrites — pooled outputs, level loops
+    without read-backs, own radix sort, positions from the SAH, own tree by copy, picks up front, two streams — changed no word of any
+    array.  A rebuild gives the same, and so does every fallback of the default builder: the bottom-up walk for the own tree, one
+    stream, and the 64-bit material sort that a collision of 32-bit keys falls back to (forced here by keeping 2 bits of the key)."""
+    import json, os
+    from conftest import ROOT
+    from metalpathtracer_amd import host
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "devbuild_digests.json")))["%s/%s" % (name, builder)]
+    monkeypatch.setenv("MPT_GPU_BUILD", builder)
+    sc = host.Scene()
+    st, log = host.SceneLoader.LoadSceneFromXML(scene_path(name), sc)
+    assert st == 0, log
+    prims, mats = sc.packed_primitives()
+    names = "nodes prims mats own refleaf refbox always ref_bvh ref_idx n_nodes n_prims n_mats n_own n_leaves n_always depth".split()
+    for k in range(2):
+        gpu_ctx.build_and_upload(prims, mats)
+        got = _digest(gpu_ctx)
+        assert got == want, "build %d: other arrays: %s" % (k, [n for n, a, b in zip(names, got, want) if a != b])
+    if builder == "sah":
+        for env, val in (("MPT_OWN_TREE_WALK", "1"), ("MPT_BUILD_ONE_STREAM", "1"), ("MPT_DEBUG_MAT_KEY_BITS", "2")):
+            monkeypatch.setenv(env, val)
+            gpu_ctx.build_and_upload(prims, mats)
+            got = _digest(gpu_ctx)
+            monkeypatch.delenv(env)
+            assert got == want, "%s: other arrays: %s" % (env, [n for n, a, b in zip(names, got, want) if a != b])
+
+
 @pytest.mark.parametrize("builder", ["sah", "sah+refit", "sah+sah", "ploc", "lbvh"])
 @pytest.mark.parametrize("name,bsdf", [("scene.xml", 0), ("glass.xml", 1), ("bunny20.xml", 0), ("cornell.xml", 0)])
 def test_build_and_upload_renders_the_oracle_image_of_its_own_tree(gpu_ctx, name, bsdf, builder, monkeypatch):
