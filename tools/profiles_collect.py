@@ -22,7 +22,7 @@ mem["note"] = ("memory-pipe counters of ONE k_ordered launch on bunny x20 (64 sp
                "L2 at four; one rocprofv3 --pmc pass per set, a failed pass fails the script).  TCP_TOTAL_CACHE_ACCESSES / TCP_TA_TCP_STATE_READ = tag look-ups per wave load instruction.")
 json.dump(mem, open(os.path.join(P, tag + "_mem_ordered_bunny20.json"), "w"), indent=1)
 for f in ("bench_kernel_stats.csv", "devbuild_kernel_stats.csv", "bench_under_rocprof.json", "bench.json", "step_table.json", "step_table.txt",
-          "ot_times_bunny20.json", "ot_times_bunny20.txt", "ot_times_config4.txt", "ot_lds_share.txt", "draw_fps.txt", "inkernel_clock.txt", "devbuild.txt", "devbuild_timeline.txt", "shard_time.txt", "depth_work.txt", "configs.txt"):
+          "ot_times_bunny20.json", "ot_times_bunny20.txt", "ot_times_config4.txt", "ot_lds_share.txt", "draw_fps.txt", "inkernel_clock.txt", "devbuild.txt", "devbuild_digests.txt", "devbuild_timeline.txt", "shard_time.txt", "depth_work.txt", "configs.txt"):
     src = os.path.join(G, "%s_%s" % (tag, f))
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "%s_%s" % (tag, f)))

@@ -38,6 +38,7 @@ BVH=3 MPT_LIB=$LIB/libmpt_hip_times.so timeout -k 10 300 python3 tools/gpu_ot_ti
 timeout -k 10 300 python3 tools/gpu_draw_fps.py > $OUT/${TAG}_draw_fps.txt 2>&1 || exit 1
 MPT_LIB=$LIB/libmpt_hip_clock.so timeout -k 10 300 python3 tools/gpu_clock.py > $OUT/${TAG}_inkernel_clock.txt 2>&1 || exit 1
 timeout -k 10 600 python3 tools/gpu_devbuild.py 64 > $OUT/${TAG}_devbuild.txt 2>&1 || exit 1
+timeout -k 10 600 python3 tools/gpu_scene_digest.py --time --check tests/golden/devbuild_digests.json > $OUT/${TAG}_devbuild_digests.txt 2>&1 || exit 1
 timeout -k 10 600 python3 tools/gpu_shard_time.py > $OUT/${TAG}_shard_time.txt 2>&1 || exit 1
 timeout -k 10 900 python3 tools/gpu_depth_work.py > $OUT/${TAG}_depth_work.txt 2>&1 || exit 1
 timeout -k 10 900 python3 tools/gpu_configs.py > $OUT/${TAG}_configs.txt 2>&1 || exit 1
