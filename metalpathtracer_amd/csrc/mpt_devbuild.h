@@ -86,24 +86,6 @@ __global__ void k_mat_scatter(const float4* mats, const uint32_t* ids, const uin
     if (j == n - 1) sc->n_mats = rank[j];
 }
 
-// ---- triangle extent (for the box padding) --------------------------------------------------------------------------------
-// (grid-stride, one atomic per wave of a bounded grid: with a wave per 64 primitives the 15,600 same-address atomics of a
-//  1 M-primitive scene took 184 us — the whole reduction reads 48 MB)
-__global__ void k_tri_extent(const float4* prims, uint32_t n, Scalars* sc) {
-    float m = 0.0f;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p0 = prims[3 * (size_t)i], p1 = prims[3 * (size_t)i + 1], p2 = prims[3 * (size_t)i + 2];
-        if ((int)p0.w == 1) {
-            const float v[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
-            for (int k = 0; k < 9; ++k)
-                if (isfinite(v[k])) m = fmaxf(m, fabsf(v[k]));
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    // (one atomic per wave that can still raise the value: 4096 same-address atomics were ~45 of the kernel's 57 us)
-    if ((threadIdx.x & 63u) == 0 && __float_as_uint(m) > __hip_atomic_load(&sc->tri_extent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&sc->tri_extent, __float_as_uint(m));
-}
-
 // ---- leaves: number them, lay their primitives out, their reference boxes, their own (sphere-free) boxes ----------------------
 __global__ void k_leaf_flags(int n, int leaf_max, const int2* range, const uint32_t* keep, uint32_t* is_leaf) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
@@ -674,13 +656,12 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     Radix R;
     Scalars* d_sc;
     mpt_lbvh::PinnedWords pinned;   // read-backs of a few words go through pinned memory (a pageable target costs ~0.3 ms per copy)
-    MPT_LB(pinned.get(pool, 0));    // (words 64 .. 95: the level slots of mpt_sah::run_sah, 128 .. 143: the collapse's, 192 ..: the scalars read at the end)
+    MPT_LB(pinned.get(pool, 0));    // (words 64 .. 111: the level slots of mpt_sah::run_sah, 160 .. 175: the collapse's, 192 ..: the scalars read at the end)
     uint32_t* pin = pinned.p;
     MPT_LB(sc.alloc(&d_sc, 1));
     MPT_LB(hipMemsetAsync(d_sc, 0, sizeof(Scalars), stream));
     MPT_LB(hand_over(stream, side, 0));   // (the caller's uploads and the zeroed scalars)
     const uint32_t B = 256, gn = (n + B - 1) / B;
-    hipLaunchKernelGGL(k_tri_extent, dim3(std::min(gn, 1024u)), dim3(B), 0, stream, (const float4*)d_prims_in, n, d_sc);
     // materials
     unsigned long long *mk, *mk2;
     uint32_t *mi, *mi2, *mhead, *mrank, *mat_of_prim;
@@ -739,7 +720,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
                            mat_of_prim, mtable, d_sc);
     }
     // the binary tree
-    MPT_LB(mpt_lbvh::build_radix(stream, sc, d_prims_in, n, leaf_max, builder, R));
+    MPT_LB(mpt_lbvh::build_radix(stream, sc, d_prims_in, n, leaf_max, builder, R, &d_sc->tri_extent));   // (k_boxes takes the triangle extent along)
     const uint32_t n_out = R.n_out;
     const size_t nn = 2 * (size_t)n - 1;
     const uint32_t gnn = (uint32_t)((nn + B - 1) / B), go = (n_out + B - 1) / B;
@@ -894,9 +875,9 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         MPT_LB(sc.alloc(&tmp, sb));
         static uint32_t s_epoch = 0;
         const uint32_t epoch = (++s_epoch & 0xFFFFu) << 16;
-        volatile unsigned long long* slots = (volatile unsigned long long*)(pin + 128);   // eight slots of (stamp << 32 | size of the next level), behind run_sah's
+        volatile unsigned long long* slots = (volatile unsigned long long*)(pin + 160);   // eight slots of (stamp << 32 | size of the next level), behind run_sah's (words 64 .. 111)
         unsigned long long* d_slots = nullptr;
-        MPT_LB(hipHostGetDevicePointer((void**)&d_slots, pin + 128, 0));
+        MPT_LB(hipHostGetDevicePointer((void**)&d_slots, pin + 160, 0));
         for (int q = 0; q < 8; ++q) slots[q] = 0ull;
         hipLaunchKernelGGL(k_collapse_picks, dim3((n + B - 1) / B), dim3(B), 0, stream, A, n, (const SahState*)d_st, refit ? 0 : 1, picks, pn);
         hipLaunchKernelGGL(k_collapse_top, dim3(1), dim3(MPT_COLLAPSE_TOP), 0, stream, A, (int)n, (const int2*)R.range, (const uint32_t*)pfirst, (const SahState*)d_st,

@@ -395,10 +395,12 @@ static int create_impl(int device_ordinal, mpt_ctx** out) {
 }
 
 // Lets go of the scene's device arrays: one by one (mpt_upload_scene's), or the block they are views into (mpt_build_and_upload's), which
-// becomes the spare block of the next build if that has none and it is not larger than 1 GiB.
+// becomes the spare block of the next build if it is not larger than 1 GiB and larger than the spare there is.
 static void free_scene_buffers(mpt_ctx* ctx, bool keep_spare) {
     if (ctx->scene_block) {
-        if (keep_spare && !ctx->spare_block && ctx->scene_block_bytes <= ((size_t)1 << 30)) {
+        // (the larger of the two is the one worth keeping: a spare that is too small for the scenes being built is never taken)
+        if (keep_spare && ctx->scene_block_bytes <= ((size_t)1 << 30) && (!ctx->spare_block || ctx->scene_block_bytes > ctx->spare_block_bytes)) {
+            hipFree(ctx->spare_block);
             ctx->spare_block = ctx->scene_block;
             ctx->spare_block_bytes = ctx->scene_block_bytes;
         } else {

@@ -88,3 +88,20 @@
         }
 #endif
 #endif
+
+// ---- device build (mpt_sah.h), round 5 ------------------------------------------------------------------------------------------------
+// REJECTED: two phases in run_sah — while a level has big tasks (>= 2048 items), the mid and small tasks it splits off WAIT in queues of
+// their own (a task carried the item buffer its items are in, SahTask::side bit 1), and one level takes all of them up together once the
+// big tasks are through.  Idea: sub-trees need nothing of one another, and the ~2000-item tasks that the last big levels shed keep five
+// levels in a row at 55-60 us each with a tenth of the chip at work; taken up together they should share those levels.  Result (same
+// box, gpurun_out/r05/s35-s36): the arrays stay the same (all 15 digests), the big levels get shorter (85 -> 71 us each, no mid / small
+// grids beside them) — and the build gets 5 % SLOWER, 2.91 -> 3.08 ms, 3.00 -> 3.17 ms: the levels after the take-up are as long as before
+// (62 / 55 / 63 / 70 / 74 us — a level lasts as long as its LONGEST task, and unbalanced splits keep tasks of ~2000 items alive for five
+// levels whenever they start), and there are two more of them, because the tasks that used to be worked off beside the big levels now
+// start later.  What those levels need is more lanes per long task (half a workgroup instead of a wave), not fewer levels.
+//
+// REJECTED: the mid and small tasks of a level in ONE kernel for every level (k_sah_tasks with both roles, instead of k_sah_level +
+// k_sah_small): the last ten levels of 1 M items 885 -> 1060 us (the two kinds of blocks share a kernel's register and LDS budget, and the
+// late levels are throughput-bound, not launch-bound); kept only for the levels that have big tasks, where the other grids are nearly empty.
+//
+// REJECTED: MPT_SAH_WAVES = 4 / 8 tasks per workgroup instead of 16: +13 % / +1 % on the build (more pushes per task).
