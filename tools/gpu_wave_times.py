@@ -5,7 +5,7 @@ from metalpathtracer_amd import capi, host
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sc = host.Scene(); st, _ = host.SceneLoader.LoadSceneFromXML(os.path.join(ROOT, "assets", "scene.xml"), sc); assert st == 0
 ctx = capi.Context(0); host.make_ready(ctx, sc, int(os.environ.get("BVH", str(host.BVH_DEVICE))))   # (the tree bench.py renders on)
-W, H = 1920, 1080
+W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
 ctx.resize(W, H); ctx.set_uniforms(host.make_uniforms(W, H, sc.getPrimitiveCount(), sc.getTriangleCount()))
 L = capi.load()
 L.mpt_debug_bind(ctx.h)
@@ -13,7 +13,7 @@ flags = capi.FLAG_COUNT_WORK if os.environ.get("COUNT") else 0
 for rep in range(2):
     if rep: L.mpt_debug_reset()
     ctx.clear_sum(); ctx.reset_stats()
-    ctx.render(rng_mode=capi.RNG_PHILOX, max_depth=8, sample_count=int(os.environ.get("SPP","64")), pipeline=2, flags=flags,
+    ctx.render(rng_mode=int(os.environ.get("RNG", str(capi.RNG_PHILOX))), max_depth=int(os.environ.get("DEPTH", "8")), sample_count=int(os.environ.get("SPP","64")), pipeline=2, flags=flags,
                shard_rank=0, shard_count=int(os.environ.get("SHARDS", "1")))   # SHARDS=8: one GPU's tile shard of an 8-GPU render
 st = ctx.stats()
 n = int(os.environ.get("WAVES", "6144"))
