@@ -105,3 +105,7 @@
 // late levels are throughput-bound, not launch-bound); kept only for the levels that have big tasks, where the other grids are nearly empty.
 //
 // REJECTED: MPT_SAH_WAVES = 4 / 8 tasks per workgroup instead of 16: +13 % / +1 % on the build (more pushes per task).
+//
+// REJECTED: four trips of loads in flight in the partition loop of the mid tasks too (as in their bounds pass): 2.87 -> 3.00 ms for 1 M
+// primitives (three of four same-box runs, gpurun_out/r05/s40): the registers it takes cost the throughput-bound late levels more than the
+// five latency-bound ones gain.  One trip ahead (kept) was worth 62 -> 55 us on those levels.
