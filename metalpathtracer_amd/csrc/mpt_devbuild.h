@@ -86,6 +86,24 @@ __global__ void k_mat_scatter(const float4* mats, const uint32_t* ids, const uin
     if (j == n - 1) sc->n_mats = rank[j];
 }
 
+// ---- triangle extent (for the box padding) --------------------------------------------------------------------------------
+// (grid-stride, one atomic per wave of a bounded grid, and only from a wave that can still raise the value: with a wave per 64 primitives
+//  the 15,600 same-address atomics of a 1 M-primitive scene took 184 us; folded into mpt_lbvh.h k_boxes — one wave per 64 primitives
+//  again — the guard's load of the hot word before the atomic made THAT kernel 14 -> 85 us.  30 us here, on the side stream, beside the tree build)
+__global__ void k_tri_extent(const float4* prims, uint32_t n, Scalars* sc) {
+    float m = 0.0f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p0 = prims[3 * (size_t)i], p1 = prims[3 * (size_t)i + 1], p2 = prims[3 * (size_t)i + 2];
+        if ((int)p0.w == 1) {
+            const float v[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
+            for (int k = 0; k < 9; ++k)
+                if (isfinite(v[k])) m = fmaxf(m, fabsf(v[k]));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63u) == 0 && __float_as_uint(m) > __hip_atomic_load(&sc->tri_extent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&sc->tri_extent, __float_as_uint(m));
+}
+
 // ---- leaves: number them, lay their primitives out, their reference boxes, their own (sphere-free) boxes ----------------------
 __global__ void k_leaf_flags(int n, int leaf_max, const int2* range, const uint32_t* keep, uint32_t* is_leaf) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
@@ -693,6 +711,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     }
     uint32_t key_shift = 0u;
     if (const char* e = getenv("MPT_DEBUG_MAT_KEY_BITS")) key_shift = 32u - (uint32_t)std::min(std::max(atoi(e), 1), 32);
+    hipLaunchKernelGGL(k_tri_extent, dim3(std::min(gn, 1024u)), dim3(B), 0, side, (const float4*)d_prims_in, n, d_sc);   // (needed by k_leaves: joins with the materials)
     hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, side, d_mats_in, n, mk, mk32, key_shift, mi);
     {
         const uint32_t *ids_sorted = mi2, *keys32_sorted = nullptr;
@@ -720,7 +739,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
                            mat_of_prim, mtable, d_sc);
     }
     // the binary tree
-    MPT_LB(mpt_lbvh::build_radix(stream, sc, d_prims_in, n, leaf_max, builder, R, &d_sc->tri_extent));   // (k_boxes takes the triangle extent along)
+    MPT_LB(mpt_lbvh::build_radix(stream, sc, d_prims_in, n, leaf_max, builder, R));
     const uint32_t n_out = R.n_out;
     const size_t nn = 2 * (size_t)n - 1;
     const uint32_t gnn = (uint32_t)((nn + B - 1) / B), go = (n_out + B - 1) / B;

@@ -34,20 +34,12 @@ __device__ __forceinline__ int f2ord(float f) {  // order-preserving float -> in
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
 // primitive boxes (Scene.h:199-209) + bounds of the box centres
-// tri_extent (may be null): bits of the largest finite |coordinate| of a triangle vertex, for the box padding of mpt_devbuild.h — taken here, where
-// the vertices are in registers anyway (a pass of its own over the 48 MB of a 1 M-primitive scene was 30 us)
-__global__ void k_boxes(const float4* prims, uint32_t n, float4* blo, float4* bhi, int* cb /* [6]: min xyz, max xyz as ordered ints */, uint32_t* tri_extent) {
+__global__ void k_boxes(const float4* prims, uint32_t n, float4* blo, float4* bhi, int* cb /* [6]: min xyz, max xyz as ordered ints */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, c[3] = {0, 0, 0};
     const bool valid = i < n;
-    float ext_max = 0.0f;
     if (valid) {
         const float4 p0 = prims[3 * (size_t)i], p1 = prims[3 * (size_t)i + 1], p2 = prims[3 * (size_t)i + 2];
-        if ((int)p0.w == 1) {
-            const float v[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
-            for (int k = 0; k < 9; ++k)
-                if (isfinite(v[k])) ext_max = fmaxf(ext_max, fabsf(v[k]));
-        }
         if ((int)p0.w == 0) {
             lo[0] = p0.x - p1.x; lo[1] = p0.y - p1.x; lo[2] = p0.z - p1.x;
             hi[0] = p0.x + p1.x; hi[1] = p0.y + p1.x; hi[2] = p0.z + p1.x;
@@ -72,11 +64,6 @@ __global__ void k_boxes(const float4* prims, uint32_t n, float4* blo, float4* bh
         blo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         bhi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
         for (int a = 0; a < 3; ++a) c[a] = 0.5f * lo[a] + 0.5f * hi[a];
-    }
-    if (tri_extent) {   // (one atomic per wave that can still raise the value: most find it raised already)
-        for (int off = 32; off > 0; off >>= 1) ext_max = fmaxf(ext_max, __shfl_xor(ext_max, off));
-        if ((threadIdx.x & 63u) == 0 && __float_as_uint(ext_max) > __hip_atomic_load(tri_extent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(tri_extent, __float_as_uint(ext_max));
     }
     if (!cb) return;   // (the top-down builder has no use for the bounds of the centroids: 94 k atomics on six words, 0.9 ms at 1 M)
     // wave reduction, then one atomic per wave and component
@@ -599,7 +586,7 @@ static hipError_t finish_radix(hipStream_t stream, Scratch& sc, Radix& R, uint32
 // d_prims: device, 3 float4 per primitive.  Leaves everything of Radix on the device; synchronises the stream once to
 // read the output node count (and once per round / level of the clustering or the SAH).
 enum { BUILDER_KARRAS = 0, BUILDER_PLOC = 1, BUILDER_SAH = 2 };
-static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, uint32_t n, int leaf_max, int builder, Radix& R, uint32_t* tri_extent = nullptr) {
+static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, uint32_t n, int leaf_max, int builder, Radix& R) {
     int *arrived;
     unsigned long long *keys, *keys2;
     uint32_t *vals0, *vals_sorted;
@@ -626,11 +613,14 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
     MPT_LB(sc.alloc(&R.keep, nn + 1));
     MPT_LB(sc.alloc(&R.index, nn + 1));
     const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-    MPT_LB(hipMemcpyAsync(R.cb, init, sizeof init, hipMemcpyHostToDevice, stream));
-    MPT_LB(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
+    const bool top_down = n > 2 && builder == BUILDER_SAH;   // (needs neither the bounds of the centroids nor the refit's arrival counters)
+    if (!top_down) {
+        MPT_LB(hipMemcpyAsync(R.cb, init, sizeof init, hipMemcpyHostToDevice, stream));
+        MPT_LB(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
+    }
     const uint32_t B = 256, gn = (n + B - 1) / B, gnn = (uint32_t)((nn + B - 1) / B);
-    hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, R.blo, R.bhi, n > 2 && builder == BUILDER_SAH ? (int*)nullptr : R.cb, tri_extent);
-    if (n > 2 && builder == BUILDER_SAH) {
+    hipLaunchKernelGGL(k_boxes, dim3(gn), dim3(B), 0, stream, (const float4*)d_prims, n, R.blo, R.bhi, top_down ? (int*)nullptr : R.cb);
+    if (top_down) {
         // top-down binned SAH over the primitives (mpt_sah.h), then renumbered like the clustering's tree
         float4 *it_lo, *it_hi, *nlo0, *nhi0;
         int2* child0;
