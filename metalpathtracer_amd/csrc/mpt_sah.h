@@ -775,13 +775,17 @@ __global__ __launch_bounds__(MPT_SAH_CHUNK_THREADS) void k_big_scatter(const flo
         __syncthreads();
     }
 }
-// (a block role of k_sah_tasks below: it needs the level's k_big_count, nothing of its mid and small tasks)
-__device__ __forceinline__ void sah_big_push_thread(uint32_t t, const SahTask* tasks, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
-                                                    SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, uint32_t level, const SahFirst& fs) {
+// (a block role of k_sah_tasks below: it needs the level's k_big_count, nothing of its mid and small tasks.  A WAVE per task: the root's
+//  489 chunk counts added up by one thread were 24 us of the first level, 14 / 10 / 7 of the next)
+__device__ __forceinline__ void sah_big_push_wave(uint32_t t, const SahTask* tasks, const uint32_t* coff, const SahBig* big, const uint32_t* chunk_left, SahTask* next,
+                                                  SahTask* next_big, SahTask* next_small, SahState* st, int2* s_child, uint32_t level, const SahFirst& fs) {
     if (t >= st->cnt[level % 3u][16]) return;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t nlft = 0;
-    for (uint32_t c = coff[t]; c < coff[t + 1u]; ++c) nlft += chunk_left[c];
-    sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1], fs);
+    for (uint32_t c = coff[t] + lane; c < coff[t + 1u]; c += 64u) nlft += chunk_left[c];
+    for (int off = 32; off > 0; off >>= 1) nlft += __shfl_xor(nlft, off);
+    if (lane == 0)
+        sah_push_children(st->cnt[(level + 1u) % 3u], s_child, next, next_big, next_small, tasks[t].b, tasks[t].e, nlft, big[t].k, big[t].one[0], big[t].one[1], fs);
 }
 
 // ... and for a SMALL task (<= MPT_SAH_SMALL items: the last three or four levels, which hold most of the tree's nodes and took
@@ -954,8 +958,8 @@ __global__ __launch_bounds__(64 * MPT_SAH_WAVES) void k_sah_tasks(int n, const f
     else if (blockIdx.x < mid_blocks + small_blocks)
         sah_small_thread((blockIdx.x - mid_blocks) * (64u * MPT_SAH_WAVES) + threadIdx.x, n, in_lo, in_hi, small_tasks, st, s_child, s_lo, s_hi, lv.level, fs);
     else
-        sah_big_push_thread((blockIdx.x - mid_blocks - small_blocks) * (64u * MPT_SAH_WAVES) + threadIdx.x, big_tasks, coff, big, chunk_left, next, next_big, next_small, st,
-                            s_child, lv.level, fs);
+        sah_big_push_wave((blockIdx.x - mid_blocks - small_blocks) * MPT_SAH_WAVES + (threadIdx.x >> 6), big_tasks, coff, big, chunk_left, next, next_big, next_small, st,
+                          s_child, lv.level, fs);
 }
 
 // ... and the mid and the small tasks on their own, for the levels that have no big task any more (most of the tree's nodes are made there:
@@ -1074,7 +1078,7 @@ static hipError_t run_sah(hipStream_t stream, Scratch& sc, uint32_t* pin, int to
             // ... and ONE launch for the children of the big tasks and the level's mid and small tasks (k_sah_tasks)
             constexpr uint32_t TH = 64u * MPT_SAH_WAVES;
             const uint32_t mid_blocks = (b_mid + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES, small_blocks = (uint32_t)(((size_t)b_small * MPT_SAH_SMALL + TH - 1) / TH),
-                           push_blocks = (b_big + TH - 1) / TH;
+                           push_blocks = (b_big + MPT_SAH_WAVES - 1) / MPT_SAH_WAVES;
             hipLaunchKernelGGL(k_sah_tasks, dim3(mid_blocks + small_blocks + push_blocks), dim3(TH), 0, stream, n, (const float4*)it_lo_a, (const float4*)it_hi_a, it_lo_b,
                                it_hi_b, (const SahTask*)tasks_a, (const SahTask*)small_a, (const SahTask*)big_a, tasks_b, big_b, small_b, T.st, T.child, T.lo, T.hi,
                                (const uint32_t*)coff, (const SahBig*)bigs, (const uint32_t*)chunk_left, mid_blocks, small_blocks, take(), T.first);
