@@ -144,6 +144,57 @@ def test_device_build_writes_the_recorded_arrays(gpu_ctx, name, builder, monkeyp
             assert got == want, "%s: other arrays: %s" % (env, [n for n, a, b in zip(names, got, want) if a != b])
 
 
+def test_device_builds_of_two_contexts_at_once_and_of_alternating_sizes_write_the_recorded_arrays():
+    """The builder's pooled state under the uses a host program makes of it.  (a) Two contexts of one GPU build in two threads at the same
+    time, five times each — every build has its own scratch pool, pinned words, second stream and output block, and only the epoch
+    counters of the level loops are shared: every build writes the recorded arrays.  (b) One context builds a large scene, a small one
+    and the large one again: the output block of the scene before is the next build's when it is large enough (and the larger of the
+    two is the one kept), a scene uploaded through mpt_upload_scene in between owns its arrays one by one — recorded arrays every time,
+    and mpt_scene_digest of the uploaded scene reports no reference-format tree."""
+    import json, os, threading
+    from conftest import ROOT
+    from metalpathtracer_amd import capi, host
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "devbuild_digests.json")))
+    scenes = {}
+    for name in ("bunny20.xml", "scene.xml"):
+        sc = host.Scene()
+        st, log = host.SceneLoader.LoadSceneFromXML(scene_path(name), sc)
+        assert st == 0, log
+        scenes[name] = (sc, sc.packed_primitives())
+    os.environ.pop("MPT_GPU_BUILD", None)
+    # (a)
+    bad = []
+    def work(name):
+        try:
+            ctx = capi.Context(0)
+            for k in range(5):
+                ctx.build_and_upload(*scenes[name][1])
+                if _digest(ctx) != want[name + "/sah"]:
+                    bad.append((name, k))
+            ctx.close()
+        except Exception as e:   # noqa: BLE001 — reported by the main thread
+            bad.append((name, repr(e)))
+    th = [threading.Thread(target=work, args=(n,)) for n in ("bunny20.xml", "scene.xml")]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not bad, bad
+    # (b)
+    ctx = capi.Context(0)
+    try:
+        for name in ("bunny20.xml", "scene.xml", "bunny20.xml", "scene.xml", "scene.xml", "bunny20.xml"):
+            ctx.build_and_upload(*scenes[name][1])
+            assert _digest(ctx) == want[name + "/sah"], name
+        sc = scenes["scene.xml"][0]
+        sc.buildBVH()
+        ctx.upload_scene(*sc.buffers())
+        d = ctx.scene_digest()
+        assert d[7] == 0 and d[8] == 0 and d[0] != 0 and d[10] == sc.getPrimitiveCount()
+        ctx.build_and_upload(*scenes["bunny20.xml"][1])
+        assert _digest(ctx) == want["bunny20.xml/sah"]
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("builder", ["sah", "sah+refit", "sah+sah", "ploc", "lbvh"])
 @pytest.mark.parametrize("name,bsdf", [("scene.xml", 0), ("glass.xml", 1), ("bunny20.xml", 0), ("cornell.xml", 0)])
 def test_build_and_upload_renders_the_oracle_image_of_its_own_tree(gpu_ctx, name, bsdf, builder, monkeypatch):
