@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
+
 #include "mpt_accel.h"
 #include "mpt_device.h"
 #include "mpt_lbvh.h"
@@ -624,8 +626,11 @@ static size_t out_block_bytes(uint32_t n) {
 }
 
 // spare / spare_bytes (in, out): a device allocation the caller has no more use for — taken for the outputs if it is large enough.
-static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint, Built& out,
-                             mpt_lbvh::ScratchPool* pool, void** spare, size_t* spare_bytes, bool wide_mat_sort, bool* mat_collision) {
+// mats_host (may be null): the caller's material array in host memory, NOT yet copied to d_mats_in — the copy is then made here, on the side
+// stream by a helper thread (a copy from pageable memory keeps its host thread for its whole length: 1.1 ms for the 32 MB of 1 M
+// primitives), while this thread drives the tree build on the main stream.
+static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, float4* d_mats_in, const float* mats_host, uint32_t n, int leaf_max, int builder,
+                             uint32_t n_spheres_hint, Built& out, mpt_lbvh::ScratchPool* pool, void** spare, size_t* spare_bytes, bool wide_mat_sort, bool* mat_collision) {
     Scratch sc(pool);
     // Two streams (round 5): the material chain (hash, sort, table: ~0.19 ms of small kernels for 1 M primitives) needs nothing of the tree until
     // the leaves are written, and the threaded tree (depths, their sort, the emission: ~0.13 ms) nothing of the own tree's collapse — each runs
@@ -637,6 +642,11 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         hipStream_t s;
         ~SideGuard() { if (s) hipStreamSynchronize(s); }
     } side_guard{two ? side : nullptr};
+    struct Helper {   // (joined before the side stream is drained and the scratch goes back: declared after both)
+        std::thread t;
+        hipError_t err = hipSuccess;
+        ~Helper() { if (t.joinable()) t.join(); }
+    } helper;
     auto hand_over = [&](hipStream_t from, hipStream_t to, int e) -> hipError_t {   // what `to` does next comes after what `from` has been given so far
         if (!two) return hipSuccess;
         MPT_LB(hipEventRecord(pool->ev[e], from));
@@ -711,32 +721,49 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     }
     uint32_t key_shift = 0u;
     if (const char* e = getenv("MPT_DEBUG_MAT_KEY_BITS")) key_shift = 32u - (uint32_t)std::min(std::max(atoi(e), 1), 32);
-    hipLaunchKernelGGL(k_tri_extent, dim3(std::min(gn, 1024u)), dim3(B), 0, side, (const float4*)d_prims_in, n, d_sc);   // (needed by k_leaves: joins with the materials)
-    hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, side, d_mats_in, n, mk, mk32, key_shift, mi);
-    {
+    // (everything the chain needs is allocated here, by this thread: the scratch allocator is not for two)
+    char *sort_tmp = nullptr, *scan_tmp = nullptr;
+    size_t sort_bytes = 0, scan_bytes = 0;
+    mpt_radix::RadixTemp RT;
+    if (wide_mat_sort) {
+        MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, mk, mk2, mi, mi2, (int)n, 0, 64, side));
+        MPT_LB(sc.alloc(&sort_tmp, sort_bytes));
+    } else {
+        MPT_LB(mpt_radix::radix_reserve(sc, n, side, RT));
+    }
+    MPT_LB(hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, mhead, mrank, (int)n, side));
+    MPT_LB(sc.alloc(&scan_tmp, scan_bytes));
+    auto mats_chain = [&]() -> hipError_t {
+        hipLaunchKernelGGL(k_tri_extent, dim3(std::min(gn, 1024u)), dim3(B), 0, side, (const float4*)d_prims_in, n, d_sc);   // (needed by k_leaves: joins with the materials)
+        hipLaunchKernelGGL(k_mat_hash, dim3(gn), dim3(B), 0, side, (const float4*)d_mats_in, n, mk, mk32, key_shift, mi);
         const uint32_t *ids_sorted = mi2, *keys32_sorted = nullptr;
         if (wide_mat_sort) {
-            size_t bytes = 0;
-            MPT_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, side));
-            char* tmp;
-            MPT_LB(sc.alloc(&tmp, bytes));
-            MPT_LB(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, side));
+            size_t bytes = sort_bytes;
+            MPT_LB(hipcub::DeviceRadixSort::SortPairs(sort_tmp, bytes, mk, mk2, mi, mi2, (int)n, 0, 64, side));
         } else {
-            mpt_radix::RadixTemp RT;
-            MPT_LB(mpt_radix::radix_reserve(sc, n, side, RT));
             bool second = false;
             MPT_LB(mpt_radix::radix_sort_pairs(side, RT, mk32, mi, mk32s, mi2, n, 4, &second));
             ids_sorted = second ? mi2 : mi;
             keys32_sorted = second ? mk32s : mk32;
         }
-        hipLaunchKernelGGL(k_mat_heads, dim3(gn), dim3(B), 0, side, d_mats_in, ids_sorted, keys32_sorted, n, mhead, d_sc);
-        size_t sb = 0;
-        MPT_LB(hipcub::DeviceScan::InclusiveSum(nullptr, sb, mhead, mrank, (int)n, side));
-        char* tmp2;
-        MPT_LB(sc.alloc(&tmp2, sb));
-        MPT_LB(hipcub::DeviceScan::InclusiveSum(tmp2, sb, mhead, mrank, (int)n, side));
-        hipLaunchKernelGGL(k_mat_scatter, dim3(gn), dim3(B), 0, side, d_mats_in, ids_sorted, (const uint32_t*)mhead, (const uint32_t*)mrank, n,
+        hipLaunchKernelGGL(k_mat_heads, dim3(gn), dim3(B), 0, side, (const float4*)d_mats_in, ids_sorted, keys32_sorted, n, mhead, d_sc);
+        size_t sb = scan_bytes;
+        MPT_LB(hipcub::DeviceScan::InclusiveSum(scan_tmp, sb, mhead, mrank, (int)n, side));
+        hipLaunchKernelGGL(k_mat_scatter, dim3(gn), dim3(B), 0, side, (const float4*)d_mats_in, ids_sorted, (const uint32_t*)mhead, (const uint32_t*)mrank, n,
                            mat_of_prim, mtable, d_sc);
+        return hipGetLastError();
+    };
+    if (mats_host && two && (size_t)n * 32 >= ((size_t)1 << 20) && getenv("MPT_BUILD_NO_HELPER") == nullptr) {   // (below 1 MB the thread costs what the copy does)
+        int dev = 0;
+        MPT_LB(hipGetDevice(&dev));
+        helper.t = std::thread([&, dev]() {
+            helper.err = hipSetDevice(dev);
+            if (helper.err == hipSuccess) helper.err = hipMemcpyAsync(d_mats_in, mats_host, (size_t)n * 32, hipMemcpyHostToDevice, side);
+            if (helper.err == hipSuccess) helper.err = mats_chain();
+        });
+    } else {
+        if (mats_host) MPT_LB(hipMemcpyAsync(d_mats_in, mats_host, (size_t)n * 32, hipMemcpyHostToDevice, side));
+        MPT_LB(mats_chain());
     }
     // the binary tree
     MPT_LB(mpt_lbvh::build_radix(stream, sc, d_prims_in, n, leaf_max, builder, R));
@@ -790,6 +817,8 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp2, sb, cnt, pos, (int)nl, stream));
         hipLaunchKernelGGL(k_pfirst_scatter, dim3(gl), dim3(B), 0, stream, nl, (const uint32_t*)node_s, (const uint32_t*)pos, pfirst);
     }
+    if (helper.t.joinable()) helper.t.join();   // (the side stream has been GIVEN everything up to the material table)
+    MPT_LB(helper.err);
     MPT_LB(hand_over(side, stream, 1));   // (mat_of_prim)
     hipLaunchKernelGGL(k_leaves, dim3(gnn), dim3(B), 0, stream, (int)n, leaf_max, (const int2*)R.range, (const uint32_t*)is_leaf, (const uint32_t*)leaf_id,
                        (const uint32_t*)R.vals, (const float4*)d_prims_in, (const uint32_t*)mat_of_prim, (const float4*)R.nlo, (const float4*)R.nhi,
@@ -953,17 +982,17 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, const float
     *mat_collision = h.mat_collision != 0u;
     return hipSuccess;
 }
-static hipError_t build(hipStream_t stream, float4* d_prims_in, const float4* d_mats_in, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint, Built& out,
-                        mpt_lbvh::ScratchPool* pool = nullptr, void** spare = nullptr, size_t* spare_bytes = nullptr) {
+static hipError_t build(hipStream_t stream, float4* d_prims_in, float4* d_mats_in, const float* mats_host, uint32_t n, int leaf_max, int builder, uint32_t n_spheres_hint,
+                        Built& out, mpt_lbvh::ScratchPool* pool = nullptr, void** spare = nullptr, size_t* spare_bytes = nullptr) {
     bool collision = false;
-    MPT_LB(build_pass(stream, d_prims_in, d_mats_in, n, leaf_max, builder, n_spheres_hint, out, pool, spare, spare_bytes, false, &collision));
+    MPT_LB(build_pass(stream, d_prims_in, d_mats_in, mats_host, n, leaf_max, builder, n_spheres_hint, out, pool, spare, spare_bytes, false, &collision));
     if (!collision) return hipSuccess;
     // two different materials share the upper half of their hashes (one scene in ~2^33 / materials^2): once more, sorted on all 64 bits,
     // into the same block
     void* block = out.block;
     size_t bytes = out.block_bytes;
     out = Built{};
-    const hipError_t e = build_pass(stream, d_prims_in, d_mats_in, n, leaf_max, builder, n_spheres_hint, out, pool, &block, &bytes, true, &collision);
+    const hipError_t e = build_pass(stream, d_prims_in, d_mats_in, nullptr, n, leaf_max, builder, n_spheres_hint, out, pool, &block, &bytes, true, &collision);   // (the materials are on the device by now)
     if (block) hipFree(block);   // (not taken: the pass failed before it got there)
     return e;
 }

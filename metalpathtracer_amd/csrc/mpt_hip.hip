@@ -1822,7 +1822,6 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     HIPCHK(d_p.alloc((size_t)n * 48));
     HIPCHK(d_m.alloc((size_t)n * 32));
     HIPCHK(hipMemcpyAsync(d_p.p, prims, (size_t)n * 48, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_m.p, mats, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
     const int leaf_max = gpu_leaf_max(n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(hipEventCreate(&e0));
@@ -1832,7 +1831,8 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     }
     hipEventRecord(e0, ctx->stream);
     mpt_devbuild::Built b;
-    hipError_t e = mpt_devbuild::build(ctx->stream, (float4*)d_p.p, (const float4*)d_m.p, n, leaf_max, gpu_builder(), n_spheres, b, &ctx->build_pool, &ctx->spare_block,
+    // (the materials are copied by the build itself, on its second stream, beside the tree build: mpt_devbuild.h build_pass)
+    hipError_t e = mpt_devbuild::build(ctx->stream, (float4*)d_p.p, (float4*)d_m.p, mats, n, leaf_max, gpu_builder(), n_spheres, b, &ctx->build_pool, &ctx->spare_block,
                                        &ctx->spare_block_bytes);
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);

@@ -120,7 +120,7 @@ def test_device_build_writes_the_recorded_arrays(gpu_ctx, name, builder, monkeyp
     round 5's first half (tools/gpu_scene_digest.py --write, commit 192df6b): the builder's later rewrites — pooled outputs, level loops
     without read-backs, own radix sort, positions from the SAH, own tree by copy, picks up front, two streams — changed no word of any
     array.  A rebuild gives the same, and so does every fallback of the default builder: the bottom-up walk for the own tree, one
-    stream, and the 64-bit material sort that a collision of 32-bit keys falls back to (forced here by keeping 2 bits of the key)."""
+    stream, the material upload by the calling thread, and the 64-bit material sort that a collision of 32-bit keys falls back to (forced here by keeping 2 bits of the key)."""
     import json, os
     from conftest import ROOT
     from metalpathtracer_amd import host
@@ -136,7 +136,7 @@ def test_device_build_writes_the_recorded_arrays(gpu_ctx, name, builder, monkeyp
         got = _digest(gpu_ctx)
         assert got == want, "build %d: other arrays: %s" % (k, [n for n, a, b in zip(names, got, want) if a != b])
     if builder == "sah":
-        for env, val in (("MPT_OWN_TREE_WALK", "1"), ("MPT_BUILD_ONE_STREAM", "1"), ("MPT_DEBUG_MAT_KEY_BITS", "2")):
+        for env, val in (("MPT_OWN_TREE_WALK", "1"), ("MPT_BUILD_ONE_STREAM", "1"), ("MPT_BUILD_NO_HELPER", "1"), ("MPT_DEBUG_MAT_KEY_BITS", "2")):
             monkeypatch.setenv(env, val)
             gpu_ctx.build_and_upload(prims, mats)
             got = _digest(gpu_ctx)
