@@ -787,7 +787,10 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, float4* d_m
         MPT_LB(sc.alloc(&tmp, sb));
         MPT_LB(hipcub::DeviceScan::ExclusiveSum(tmp, sb, is_leaf, leaf_id, (int)nn + 1, stream));
     }
-    const int use_always = n_spheres_hint <= MPT_ACCEL_MAX_ALWAYS ? 1 : 0;
+    // (n_spheres_hint = 0xFFFFFFFF: not counted by the caller — the top-down builder has counted them on the device)
+    const uint32_t n_sph = n_spheres_hint != 0xFFFFFFFFu ? n_spheres_hint : R.n_spheres;
+    if (n_sph == 0xFFFFFFFFu) return hipErrorInvalidValue;
+    const int use_always = n_sph <= MPT_ACCEL_MAX_ALWAYS ? 1 : 0;
     // where each leaf's records go (see k_leaf_keys)
     uint32_t* pfirst;
     MPT_LB(sc.alloc(&pfirst, nn));
@@ -854,7 +857,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, float4* d_m
     // (the builder's own tree serves when its SAH nodes hold no sphere — the builder hangs up to 16 spheres under the root,
     //  mpt_lbvh.h — or when no always list is used; with spheres inside the SAH their boxes shape the top splits, which the own
     //  tree leaves out: a second SAH over the leaves then.  MPT_OWN_TREE = refit | sah forces either way)
-    bool refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && (R.spheres_hoisted || n_spheres_hint == 0 || !use_always);
+    bool refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && (R.spheres_hoisted || n_sph == 0 || !use_always);
     if (const char* e = getenv("MPT_OWN_TREE")) refit = builder == mpt_lbvh::BUILDER_SAH && n > 2 && strcmp(e, "refit") == 0;
     if (refit) {
         int *eff, *arrived;
@@ -869,7 +872,7 @@ static hipError_t build_pass(hipStream_t stream, float4* d_prims_in, float4* d_m
         MPT_LB(hipMemsetAsync(s_child, 0xFF, (size_t)n * sizeof(int2), stream));   // (children -1: a node nobody made — k_collapse_picks)
         // (the copy is valid when every leaf's own box is its reference box or, in the chain of hoisted items, empty: spheres hoisted or none
         //  — with spheres INSIDE the SAH's leaves and no always list the boxes agree too, but then nothing marks the chain: the walk)
-        const bool fast = (R.spheres_hoisted || n_spheres_hint == 0) && getenv("MPT_OWN_TREE_WALK") == nullptr;
+        const bool fast = (R.spheres_hoisted || n_sph == 0) && getenv("MPT_OWN_TREE_WALK") == nullptr;
         if (fast) {
             hipLaunchKernelGGL(k_own_copy, dim3((n + B - 1) / B), dim3(B), 0, stream, (int)n, (const int2*)R.child, (const uint32_t*)R.keep, (const uint32_t*)is_leaf,
                                (const float4*)R.nlo, (const float4*)R.nhi, (const Scalars*)d_sc, s_lo, s_hi, s_child);

@@ -169,6 +169,8 @@ struct mpt_ctx {
     // so a rebuild allocates nothing and a failed build leaves the old scene intact.  Scenes of mpt_upload_scene own their arrays one by one.
     void* scene_block = nullptr;
     void* spare_block = nullptr;
+    void* in_block = nullptr;          // device staging of mpt_build_and_upload's input arrays, kept between builds
+    size_t in_block_bytes = 0;
     size_t scene_block_bytes = 0, spare_block_bytes = 0;
     OtBudgets ot_budgets = default_ot_budgets();
     float tri_extent = 0.0f, acc_eps_abs = 0.0f, acc_cull_rel = 9.765625e-4f;
@@ -446,6 +448,7 @@ extern "C" int mpt_destroy(mpt_ctx* ctx) {
         if (L.stream) hipStreamSynchronize(L.stream);
     free_scene_buffers(ctx, false);
     hipFree(ctx->spare_block);
+    hipFree(ctx->in_block);
     hipFree(ctx->d_accum[0]);
     hipFree(ctx->d_accum[1]);
     hipFree(ctx->d_sum_own);
@@ -1816,11 +1819,35 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
     }
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = (uint32_t)n_prims;
-    uint32_t n_spheres = 0;   // (whether the always list can be used decides the own boxes of the leaves that hold spheres)
-    for (uint32_t i = 0; i < n; ++i) n_spheres += (int)prims[12 * (size_t)i + 3] != 1 ? 1u : 0u;
-    DevBuf d_p, d_m;
-    HIPCHK(d_p.alloc((size_t)n * 48));
-    HIPCHK(d_m.alloc((size_t)n * 32));
+    // (whether the always list can be used decides the own boxes of the leaves that hold spheres.  The default builder counts the spheres on
+    //  the device, in a kernel it runs anyway; a pass of the host over the 48 MB of 1 M primitives was 0.4 ms of the call)
+    uint32_t n_spheres = 0xFFFFFFFFu;
+    if (!(gpu_builder() == mpt_lbvh::BUILDER_SAH && n > 2)) {
+        n_spheres = 0;
+        for (uint32_t i = 0; i < n; ++i) n_spheres += (int)prims[12 * (size_t)i + 3] != 1 ? 1u : 0u;
+    }
+    // the staging buffer of the inputs is kept between builds (<= 1 GiB): two hipMallocs and two hipFrees of 80 MB were 0.3 ms of the call
+    const size_t in_bytes = (size_t)n * 80;
+    if (ctx->in_block_bytes < in_bytes) {
+        hipFree(ctx->in_block);
+        ctx->in_block = nullptr;
+        ctx->in_block_bytes = 0;
+        HIPCHK(hipMalloc(&ctx->in_block, in_bytes));
+        ctx->in_block_bytes = in_bytes;
+    }
+    struct InBuf {
+        void* p;
+    } d_p{ctx->in_block}, d_m{(char*)ctx->in_block + (size_t)n * 48};
+    struct InRelease {   // (a buffer too large to keep goes when the call ends)
+        mpt_ctx* c;
+        ~InRelease() {
+            if (c->in_block_bytes > ((size_t)1 << 30)) {
+                hipFree(c->in_block);
+                c->in_block = nullptr;
+                c->in_block_bytes = 0;
+            }
+        }
+    } in_release{ctx};
     HIPCHK(hipMemcpyAsync(d_p.p, prims, (size_t)n * 48, hipMemcpyHostToDevice, ctx->stream));
     const int leaf_max = gpu_leaf_max(n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1844,6 +1871,7 @@ static int build_and_upload_impl(mpt_ctx* ctx, const float* prims, const float* 
         b.release();
         return fail(ctx, MPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
     }
+    if (n_spheres == 0xFFFFFFFFu) n_spheres = b.n_spheres;
     if (b.n_spheres != n_spheres) {
         b.release();
         return fail(ctx, MPT_ERR_HIP, "GPU BVH build: sphere count mismatch (internal)");

@@ -457,7 +457,7 @@ __global__ void k_hoist_median(int n, HoistState* st) {   // one thread: the med
     st->n_huge = huge;   // (counts huge spheres too: an upper bound of the huge triangles, exact when the spheres are small)
 }
 // flag = 1: the item takes part in the SAH; 0: it hangs under the root
-__global__ void k_tri_flags(int n, const float4* prims, const float4* blo, const float4* bhi, HoistState* st, uint32_t* flag) {
+__global__ void k_tri_flags(int n, const float4* prims, const float4* blo, const float4* bhi, HoistState* st, uint32_t* flag, uint32_t* n_sph_out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool with_huge = st->n_sph + st->n_huge <= MPT_LBVH_HOIST_MAX && st->n_huge != 0u;
     if (p < n) {
@@ -468,6 +468,7 @@ __global__ void k_tri_flags(int n, const float4* prims, const float4* blo, const
     if (p == n) {
         flag[n] = 0u;
         st->mode = with_huge ? 2u : 1u;
+        *n_sph_out = st->n_sph;   // (read back with the item count: the caller need not count the spheres on the host)
     }
 }
 __global__ void k_prim_items_hoisted(int n, const float4* blo, const float4* bhi, const uint32_t* flag, const uint32_t* rank, float4* it_lo, float4* it_hi,
@@ -560,6 +561,7 @@ struct Radix {
     int *cb = nullptr;                       // centroid bounds (ordered ints)
     uint32_t n_out = 0;                      // output nodes (read back)
     bool spheres_hoisted = false;            // builder "sah": the spheres hang under the root, the SAH nodes hold triangles only
+    uint32_t n_spheres = 0xFFFFFFFFu;        // builder "sah": primitives that are not triangles, counted on the device (other builders: not known here)
     uint32_t n_hoisted = 0;                  // ... how many items hang there (spheres and huge triangles: a chain of n_hoisted - 1 nodes under the root)
 };
 
@@ -637,14 +639,14 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
         uint32_t *flag, *rank, *sph;
         HoistState* hoist;
         MPT_LB(sc.alloc(&flag, (size_t)n + 1));
-        MPT_LB(sc.alloc(&rank, (size_t)n + 1));
+        MPT_LB(sc.alloc(&rank, (size_t)n + 2));   // (+ 1 word behind the scan's output: the sphere count, k_tri_flags)
         MPT_LB(sc.alloc(&sph, MPT_LBVH_HOIST_MAX));
         MPT_LB(sc.alloc(&hoist, 1));
         MPT_LB(hipMemsetAsync(hoist, 0, sizeof(HoistState), stream));
         hipLaunchKernelGGL(k_hoist_hist, dim3(std::min(gn, 512u)), dim3(B), 0, stream, (int)n, (const float4*)d_prims, (const float4*)R.blo, (const float4*)R.bhi, hoist);
         hipLaunchKernelGGL(k_hoist_median, dim3(1), dim3(64), 0, stream, (int)n, hoist);
         hipLaunchKernelGGL(k_tri_flags, dim3((n + 1 + B - 1) / B), dim3(B), 0, stream, (int)n, (const float4*)d_prims, (const float4*)R.blo, (const float4*)R.bhi, hoist,
-                           flag);
+                           flag, rank + n + 1);
         {
             size_t sb = 0;
             MPT_LB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, flag, rank, (int)n + 1, stream));
@@ -652,9 +654,10 @@ static hipError_t build_radix(hipStream_t stream, Scratch& sc, float4* d_prims, 
             MPT_LB(sc.alloc(&stmp, sb));
             MPT_LB(hipcub::DeviceScan::ExclusiveSum(stmp, sb, flag, rank, (int)n + 1, stream));
         }
-        MPT_LB(hipMemcpyAsync(pinned.p, rank + n, 4, hipMemcpyDeviceToHost, stream));
+        MPT_LB(hipMemcpyAsync(pinned.p, rank + n, 8, hipMemcpyDeviceToHost, stream));
         MPT_LB(hipStreamSynchronize(stream));
         const uint32_t nt = pinned.p[0], ns = n - nt;
+        R.n_spheres = pinned.p[1];
         mpt_sah::SahTree T;
         uint32_t *first_inner, *first_item;
         MPT_LB(sc.alloc(&first_inner, n));
