@@ -2,7 +2,7 @@
 gaps in front of its launches.   usage: python tools/trace_timeline.py <kernel_trace.csv> [first-kernel-name]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-first = sys.argv[2] if len(sys.argv) > 2 else "k_tri_extent"
+first = sys.argv[2] if len(sys.argv) > 2 else "k_boxes"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 seg = rows[idx[-1]:]
